@@ -1,0 +1,310 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the REAL reference (read-only at /root/reference) on CPU.
+
+Run in the build container only:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Outputs tests/golden/*.npz (data only: seeded inputs, weights, and what the reference computed).
+The reference never travels to the GPU box; tests read only these files.
+"""
+import contextlib
+import copy
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from src.probability import depth_categorical, depth_categorical_VI, homo_Gauss_mloglike  # noqa: E402
+    from src.DUN.training_wrappers import DUN, DUN_VI  # noqa: E402
+    from src.DUN.stochastic_fc_models import arq_uncert_fc_resnet, arq_uncert_fc_MLP  # noqa: E402
+    from src.datasets.additional_gap_loader import load_wiggle  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def put_sd(out, prefix, sd):
+    for k, v in sd.items():
+        out[prefix + k] = npy(v)
+
+
+def synthetic_regression(B, din, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, din, generator=g)
+    w = torch.randn(din, 1, generator=g) / np.sqrt(din)
+    y = torch.tanh(x @ w) + 0.1 * torch.randn(B, 1, generator=g)
+    return x, y
+
+
+def build(cfg):
+    torch.manual_seed(cfg["seed"])
+    ctor = arq_uncert_fc_MLP if cfg.get("mlp") else arq_uncert_fc_resnet
+    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"], w_prior=None, BMA_prior=False)
+    D = cfg["L"] + 1
+    prior = cfg.get("prior") or [1.0 / D] * D
+    if cfg["vi"]:
+        pm = quiet(depth_categorical_VI, prior, cuda=False)
+        cls = DUN_VI
+    else:
+        pm = quiet(depth_categorical, prior, cuda=False)
+        cls = DUN
+    net = quiet(cls, model, pm, cfg["N"], lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"],
+                cuda=False, regression=cfg["regression"], pred_sig=cfg.get("pred_sig"))
+    g = torch.Generator().manual_seed(cfg["seed"] + 1000)
+    if cfg["vi"]:
+        pm.q_logits.data = 0.1 * torch.randn(D, generator=g)
+    if cfg["regression"] and cfg.get("pred_sig") is None:
+        net.f_neg_loglike.log_std.data = 0.05 * torch.randn(cfg["O"], generator=g)
+    # non-trivial BN affine + running stats so eval-mode parity means something
+    for blk in model.stochstic_layers:
+        bn = blk.block[2]
+        bn.weight.data = 1.0 + 0.1 * torch.randn(cfg["W"], generator=g)
+        bn.bias.data = 0.1 * torch.randn(cfg["W"], generator=g)
+        bn.running_mean.data = 0.2 * torch.rand(cfg["W"], generator=g)
+        bn.running_var.data = 0.5 + torch.rand(cfg["W"], generator=g)
+    return net
+
+
+def one_pass(net, cfg, x, y):
+    """Forward in train mode + every intermediate the hot path defines + gradients of the loss."""
+    out = {}
+    net = copy.deepcopy(net)
+    net.model.train()
+    model, pm = net.model, net.prob_model
+    D = cfg["L"] + 1
+    act_vec = model.forward(x)
+    act_vec.retain_grad()
+    prior = model.get_w_prior_loglike(k=None)
+    B = x.shape[0]
+    yy = y
+    rep = [D] + [1] * (len(yy.shape) - 1)
+    ll = -net.f_neg_loglike(act_vec.view(D * B, -1), yy.repeat(*rep)).view(D, B)
+    joint = pm.get_w_joint_loglike(prior, act_vec, yy, net.f_neg_loglike, net.N_train)
+    log_marg = pm.get_marg_loglike(joint)
+    log_post = pm.get_depth_log_posterior(joint, log_marg)
+    out["act_vec"] = npy(act_vec)
+    out["loglike"] = npy(ll)
+    out["joint"] = npy(joint)
+    out["log_marg"] = npy(log_marg)
+    out["log_post"] = npy(log_post)
+    if cfg["vi"]:
+        ELBO = pm.estimate_ELBO(prior, act_vec, yy, net.f_neg_loglike, net.N_train, Beta=1)
+        out["q"] = npy(pm.get_q_probs())
+        out["KL"] = npy(pm.get_KL())
+        out["E_loglike"] = npy(pm.get_E_loglike(joint))
+        out["ELBO"] = npy(ELBO)
+        loss = -ELBO / net.N_train
+    else:
+        loss = -log_marg / net.N_train
+    out["loss"] = npy(loss)
+    loss.backward()
+    out["g/act_vec"] = npy(act_vec.grad)
+    for k, p in model.named_parameters():
+        out["g/" + k] = npy(p.grad)
+    if cfg["vi"]:
+        out["g/q_logits"] = npy(pm.q_logits.grad)
+    if cfg["regression"] and cfg.get("pred_sig") is None:
+        out["g/log_std"] = npy(net.f_neg_loglike.log_std.grad)
+    put_sd(out, "sd_after_fwd/", {k: v for k, v in model.state_dict().items() if "running" in k or "tracked" in k})
+    return out
+
+
+def run_case(name, cfg, x, y, x_test=None):
+    out = {"meta": json.dumps(cfg)}
+    net = build(cfg)
+    if not cfg["regression"]:
+        y = y.long()
+    out["x"], out["y"] = npy(x), npy(y)
+    put_sd(out, "sd/", net.model.state_dict())
+    if cfg["vi"]:
+        out["q_logits0"] = npy(net.prob_model.q_logits)
+    if cfg["regression"]:
+        out["log_std0"] = npy(net.f_neg_loglike.log_std)
+    out.update(one_pass(net, cfg, x, y))
+
+    # three optimisation steps through the reference's own fit()
+    rets = []
+    posts = []
+    for _ in range(3):
+        rets.append(net.fit(x, y))
+        posts.append(npy(net.prob_model.current_posterior))
+    out["fit/ret"] = np.array(rets, dtype=np.float64)
+    out["fit/posterior"] = np.stack(posts)
+    put_sd(out, "fit/sd/", net.model.state_dict())
+    if cfg["vi"]:
+        out["fit/q_logits"] = npy(net.prob_model.q_logits)
+    if cfg["regression"]:
+        out["fit/log_std"] = npy(net.f_neg_loglike.log_std)
+
+    # inference API after training
+    xt = x if x_test is None else x_test
+    out["x_test"] = npy(xt)
+    out["eval/ret"] = np.array(net.eval(x, y), dtype=np.float64)
+    out["layer_predict"] = npy(net.layer_predict(xt))
+    if cfg["regression"]:
+        mu, std = net.predict(xt, get_std=True)
+        out["pred/mu"], out["pred/std"] = npy(mu), npy(std)
+        mu, mstd = net.predict(xt, get_std=True, return_model_std=True)
+        out["pred/model_std"] = npy(mstd)
+        out["pred/plain"] = npy(net.predict(xt))
+        if cfg["L"] >= 2 and cfg["vi"]:
+            k = cfg["L"] // 2
+            saved = net.prob_model.current_posterior
+            qk = saved[:k + 1] / saved[:k + 1].sum()
+            net.prob_model.current_posterior = qk
+            mu, mstd = net.predict(xt, depth=k, get_std=True, return_model_std=True)
+            out["pred/depth_k"] = np.array(k)
+            out["pred/depth_k_q"] = npy(qk)
+            out["pred/depth_k_mu"], out["pred/depth_k_model_std"] = npy(mu), npy(mstd)
+            net.prob_model.current_posterior = saved
+    else:
+        out["pred/plain"] = npy(net.predict(xt))
+
+    # dataset-level sweeps over a 3-batch loader whose length equals N_train
+    if cfg.get("sweep"):
+        Ns = cfg["N"]
+        assert x.shape[0] >= Ns
+        ds = torch.utils.data.TensorDataset(x[:Ns], y[:Ns])
+        bs = (Ns + 2) // 3
+        loader = torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=False)
+        post, lm = net.get_exact_d_posterior(loader, train_bn=False, logposterior=False)
+        out["sweep/posterior"], out["sweep/log_marg"] = npy(post), np.array(lm)
+        out["sweep/batch"] = np.array(bs)
+        if cfg["vi"]:
+            out["sweep/ELBO"] = np.array(net.get_exact_ELBO(loader, train_bn=False))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "fit ret", rets[-1])
+
+
+def edge_cases():
+    """Probability-module edge semantics straight from the reference classes (no network)."""
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    # (1) regression, ragged B, clamp active (exp(log_std) < 1e-4), peaked q driving one q_d below eps
+    for tag, D, B, log_std, qscale in (("clamp", 5, 37, -12.0, 1.0), ("peaked", 4, 130, 0.3, 60.0),
+                                       ("one_depth", 1, 9, -0.2, 1.0), ("one_row", 3, 1, 0.1, 1.0)):
+        act = torch.randn(D, B, 1, generator=g).requires_grad_(True)
+        y = torch.randn(B, 1, generator=g)
+        pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=False)
+        pm.q_logits.data = qscale * torch.randn(D, generator=g)
+        f = homo_Gauss_mloglike(1, None)
+        f.log_std.data = torch.tensor([log_std])
+        N = 1000
+        prior = torch.zeros(D)
+        ELBO = pm.estimate_ELBO(prior, act, y, f, N, Beta=1)
+        joint = depth_categorical.get_w_joint_loglike(prior, act, y, f, N)
+        (-ELBO / N).backward()
+        p = "reg_%s/" % tag
+        out[p + "act"], out[p + "y"] = npy(act), npy(y)
+        out[p + "q_logits"], out[p + "log_std"] = npy(pm.q_logits), npy(f.log_std)
+        out[p + "N"] = np.array(N)
+        out[p + "joint"], out[p + "ELBO"], out[p + "KL"] = npy(joint), npy(ELBO), npy(pm.get_KL())
+        out[p + "q"] = npy(pm.get_q_probs())
+        out[p + "g_act"], out[p + "g_q_logits"] = npy(act.grad), npy(pm.q_logits.grad)
+        out[p + "g_log_std"] = npy(f.log_std.grad)
+        lm = pm.get_marg_loglike(joint)
+        out[p + "log_marg"] = npy(lm)
+        out[p + "log_post"] = npy(pm.get_depth_log_posterior(joint, lm))
+        mu, std = depth_categorical.marginalise_d_predict(act.data, pm.get_q_probs(), get_std=True)
+        out[p + "mu"], out[p + "std"] = npy(mu), npy(std)
+    # (2) classification, several class counts incl. non power of two and > 64
+    for C, D, B in ((10, 12, 50), (3, 2, 7), (100, 3, 33), (1000, 2, 5)):
+        act = (3.0 * torch.randn(D, B, C, generator=g)).requires_grad_(True)
+        y = torch.randint(0, C, (B,), generator=g)
+        pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=False)
+        pm.q_logits.data = torch.randn(D, generator=g)
+        f = torch.nn.CrossEntropyLoss(reduction="none")
+        N = 5000
+        prior = torch.zeros(D)
+        ELBO = pm.estimate_ELBO(prior, act, y, f, N, Beta=1)
+        joint = depth_categorical.get_w_joint_loglike(prior, act, y, f, N)
+        (-ELBO / N).backward()
+        p = "cls_%d/" % C
+        out[p + "act"], out[p + "y"] = npy(act), npy(y)
+        out[p + "q_logits"] = npy(pm.q_logits)
+        out[p + "N"] = np.array(N)
+        out[p + "joint"], out[p + "ELBO"] = npy(joint), npy(ELBO)
+        out[p + "g_act"], out[p + "g_q_logits"] = npy(act.grad), npy(pm.q_logits.grad)
+        act2 = act.detach().clone().requires_grad_(True)
+        joint2 = depth_categorical.get_w_joint_loglike(prior, act2, y, f, N)
+        lm = pm.get_marg_loglike(joint2)
+        (-lm / N).backward()
+        out[p + "log_marg"] = npy(lm)
+        out[p + "gm_act"] = npy(act2.grad)
+        out[p + "probs"] = npy(depth_categorical.marginalise_d_predict(act.data, pm.get_q_probs(), softmax=True))
+    # (3) O=2 regression must raise in the reference
+    try:
+        act = torch.randn(3, 5, 2)
+        depth_categorical.get_w_joint_loglike(torch.zeros(3), act, torch.randn(5, 2), homo_Gauss_mloglike(2), 10)
+        out["o2_raises"] = np.array(0)
+    except RuntimeError:
+        out["o2_raises"] = np.array(1)
+    np.savez_compressed(os.path.join(HERE, "edge.npz"), **out)
+    print("wrote edge")
+
+
+def head_case():
+    """Reduced image-DUN head: shared Linear over per-depth pooled features + CE ELBO (C4/C5 shape family)."""
+    g = torch.Generator().manual_seed(11)
+    D, B, K, C = 6, 40, 512, 10
+    feat = torch.randn(D, B, K, generator=g).relu().requires_grad_(True)
+    lin = torch.nn.Linear(K, C)
+    y = torch.randint(0, C, (B,), generator=g)
+    pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=False)
+    pm.q_logits.data = 0.3 * torch.randn(D, generator=g)
+    N = 60000
+    act = lin(feat.view(D * B, K)).view(D, B, C)
+    ELBO = pm.estimate_ELBO(torch.zeros(D), act, y, torch.nn.CrossEntropyLoss(reduction="none"), N, Beta=1)
+    (-ELBO / N).backward()
+    out = dict(feat=npy(feat), w=npy(lin.weight), b=npy(lin.bias), y=npy(y), q_logits=npy(pm.q_logits),
+               N=np.array(N), act=npy(act), ELBO=npy(ELBO), g_feat=npy(feat.grad), g_w=npy(lin.weight.grad),
+               g_b=npy(lin.bias.grad), g_q_logits=npy(pm.q_logits.grad))
+    np.savez_compressed(os.path.join(HERE, "head_c10.npz"), **out)
+    print("wrote head_c10")
+
+
+def main():
+    base = dict(seed=0, O=1, vi=True, regression=True, wd=0.0)
+    X, Y = load_wiggle()
+    run_case("c1_wiggle", dict(base, din=1, W=100, L=10, N=300, lr=1e-3, momentum=0.9, wd=1e-4, sweep=True),
+             torch.from_numpy(X), torch.from_numpy(Y))
+    x, y = synthetic_regression(512, 13, 1)
+    run_case("c2_boston", dict(base, din=13, W=100, L=10, N=455, lr=1e-2, momentum=0.5), x, y)
+    x, y = synthetic_regression(512, 9, 2)
+    run_case("c2_protein", dict(base, din=9, W=100, L=10, N=41157, lr=1e-2, momentum=0.5), x, y)
+    x, y = synthetic_regression(1024, 64, 3)
+    run_case("c3_reduced", dict(base, din=64, W=256, L=3, N=1 << 20, lr=1e-2, momentum=0.5), x, y)
+    x, y = synthetic_regression(200, 5, 4)
+    run_case("mll_small", dict(base, vi=False, din=5, W=48, L=4, N=200, lr=1e-2, momentum=0.5, sweep=True), x, y)
+    x, y = synthetic_regression(96, 7, 5)
+    run_case("mlp_nores", dict(base, mlp=True, din=7, W=40, L=3, N=96, lr=1e-2, momentum=0.9, wd=1e-3), x, y)
+    x, y = synthetic_regression(64, 3, 6)
+    run_case("fixed_sig", dict(base, din=3, W=32, L=2, N=64, lr=1e-2, momentum=0.5, pred_sig=0.5), x, y)
+    g = torch.Generator().manual_seed(8)
+    xc = torch.randn(256, 20, generator=g)
+    yc = torch.randint(0, 10, (256,), generator=g)
+    run_case("cls_fc", dict(base, regression=False, din=20, O=10, W=64, L=4, N=256, lr=0.05, momentum=0.9,
+                            wd=1e-4, sweep=True), xc, yc)
+    run_case("cls_fc_mll", dict(base, regression=False, vi=False, din=20, O=10, W=64, L=4, N=256, lr=0.05,
+                                momentum=0.9), xc, yc)
+    edge_cases()
+    head_case()
+
+
+if __name__ == "__main__":
+    main()

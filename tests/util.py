@@ -1,0 +1,77 @@
+"""Shared helpers for the parity tests: golden-fixture loading and oracle construction."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import dun_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+FC_CASES = ["c1_wiggle", "c2_boston", "c2_protein", "c3_reduced", "mll_small", "mlp_nores", "fixed_sig",
+            "cls_fc", "cls_fc_mll"]
+
+
+class Case(object):
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.cfg = json.loads(str(self.z["meta"])) if "meta" in self.z.files else {}
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def has(self, k):
+        return k in self.z.files
+
+    def t(self, k):
+        return torch.from_numpy(np.array(self.z[k]))
+
+    def sub(self, prefix):
+        return {k[len(prefix):]: self.z[k] for k in self.z.files if k.startswith(prefix)}
+
+    @property
+    def D(self):
+        return self.cfg["L"] + 1
+
+    def prior(self):
+        return [1.0 / self.D] * self.D
+
+    def y(self):
+        y = self.t("y")
+        return y if self.cfg["regression"] else y.long()
+
+    def oracle_net(self, dtype=torch.float32):
+        cfg = self.cfg
+        p = O.params_from_reference_state_dict(self.sub("sd/"), cfg["L"], dtype=dtype)
+        net = O.OracleNet(p, self.prior(), cfg["N"], lr=cfg["lr"], momentum=cfg["momentum"],
+                          weight_decay=cfg["wd"], regression=cfg["regression"], vi=cfg["vi"],
+                          residual=not cfg.get("mlp", False), pred_sig=cfg.get("pred_sig"))
+        if cfg["vi"]:
+            net.q_logits = self.t("q_logits0").to(dtype)
+        if cfg["regression"]:
+            net.log_std = self.t("log_std0").to(dtype)
+        return net
+
+
+def stacked_grads_from_reference(case, prefix="g/"):
+    """Reference per-module grads -> the stacked layout of oracle/dun_amd params."""
+    g = case.sub(prefix)
+    L = case.cfg["L"]
+    out = {"w_in": g["input_layer.weight"], "b_in": g["input_layer.bias"],
+           "w_out": g["output_layer.weight"], "b_out": g["output_layer.bias"]}
+    pre = "stochstic_layers.%d.block.%d.%s"
+    if L:
+        out["w"] = np.stack([g[pre % (i, 0, "weight")] for i in range(L)])
+        out["b"] = np.stack([g[pre % (i, 0, "bias")] for i in range(L)])
+        out["gamma"] = np.stack([g[pre % (i, 2, "weight")] for i in range(L)])
+        out["beta"] = np.stack([g[pre % (i, 2, "bias")] for i in range(L)])
+    return out
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    denom = max(np.abs(b).max(), 1e-30)
+    return float(np.abs(a - b).max() / denom)
