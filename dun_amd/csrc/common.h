@@ -1,0 +1,94 @@
+// Shared device/host helpers for the dun_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dun_hip.h"
+
+namespace dun {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVE = 64;
+
+// ---- error plumbing: every extern "C" entry returns DUN_OK or an error code and records a message ----
+void set_error(const char* fmt, ...);
+
+#define DUN_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            dun::set_error(__VA_ARGS__);      \
+            return DUN_ERR_INVALID;           \
+        }                                     \
+    } while (0)
+
+#define DUN_LAUNCH_CHECK()                                                        \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            dun::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,         \
+                           hipGetErrorString(e__));                               \
+            return DUN_ERR_LAUNCH;                                                \
+        }                                                                         \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- wavefront (64 lanes) and workgroup reductions ----
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        T o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// reduce inside a power-of-two group of G consecutive lanes (G <= 64)
+template <int G, typename T>
+__device__ __forceinline__ T group_sum(T v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int G, typename T>
+__device__ __forceinline__ T group_max(T v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        T o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// sum over a workgroup of NT threads (NT multiple of 64, <= 1024); result valid in thread 0.
+// `red` is caller-provided LDS of at least NT/64 elements; the call contains two barriers.
+template <int NT, typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    T r = T(0);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += red[i];
+    }
+    return r;
+}
+
+}  // namespace dun

@@ -1,0 +1,559 @@
+// Depth-categorical probability module on device (gfx950): fused per-depth likelihood passes with the
+// matching backward, deterministic depth reductions, ELBO / exact-marginal finalisation, and the
+// depth-marginal predictor with fused train/eval metrics.
+//
+// All of these are HBM-streaming kernels: every element of act / dact is touched exactly once with
+// coalesced (16-byte where alignment allows) accesses, per-depth sums go wavefront-shuffle -> LDS -> one
+// fp64 partial per workgroup, and a second tiny kernel adds the partials in a fixed order, so results are
+// bitwise reproducible run to run (no float atomics).
+#include <math.h>
+
+#include "common.h"
+
+namespace dun {
+
+constexpr float LOG_SQRT_2PI_F = 0.91893853320467274178f;
+constexpr double LOG_SQRT_2PI_D = 0.91893853320467274178;
+constexpr int GAUSS_PER_BLOCK = 4096;  // 256 threads x float4 x 4
+constexpr int ROWS_PER_BLOCK = 256;    // softmax rows per workgroup
+
+// weight of depth d: w[d], or softmax(w)[d] when the caller hands over logits (q = softmax(q_logits)).
+// Uniform addresses: the compiler turns these into scalar loads, every thread gets the same value.
+__device__ __forceinline__ float depth_weight(const float* __restrict__ w, int w_is_logits, int D, int d) {
+    if (w == nullptr) return 0.f;
+    if (!w_is_logits) return w[d];
+    float mx = -INFINITY;
+    for (int i = 0; i < D; ++i) mx = fmaxf(mx, w[i]);
+    float s = 0.f;
+    for (int i = 0; i < D; ++i) s += expf(w[i] - mx);
+    return expf(w[d] - mx) / s;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__ act, const float* __restrict__ y,
+                                                       const float* __restrict__ log_std,
+                                                       const float* __restrict__ w, int w_is_logits, int D, int B,
+                                                       float inv_batch, float* __restrict__ dact,
+                                                       float* __restrict__ ll, double* __restrict__ partials,
+                                                       int nparts) {
+    __shared__ double red[4];
+    const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const float wd = depth_weight(w, w_is_logits, D, d);
+    const float sigma = fmaxf(expf(log_std[0]), 1e-4f);
+    const float inv_var = 1.f / (sigma * sigma);
+    const float c0 = LOG_SQRT_2PI_F + logf(sigma);
+    const float coef = -(wd * inv_batch) * inv_var;
+    const float* a_row = act + (size_t)d * B;
+    float* g_row = dact ? dact + (size_t)d * B : nullptr;
+    float* l_row = ll ? ll + (size_t)d * B : nullptr;
+    float acc = 0.f;
+    const int base = part * GAUSS_PER_BLOCK;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = base + (it * 256 + tid) * 4;
+        if (VEC) {
+            if (idx < B) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + idx);
+                const f32x4 t = *reinterpret_cast<const f32x4*>(y + idx);
+                f32x4 r = t - a;
+                acc += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+                if (g_row) *reinterpret_cast<f32x4*>(g_row + idx) = coef * r;
+                if (l_row) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = -(c0 + 0.5f * r[e] * r[e] * inv_var);
+                    *reinterpret_cast<f32x4*>(l_row + idx) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = idx + e;
+                if (i < B) {
+                    const float r = y[i] - a_row[i];
+                    acc += r * r;
+                    if (g_row) g_row[i] = coef * r;
+                    if (l_row) l_row[i] = -(c0 + 0.5f * r * r * inv_var);
+                }
+            }
+        }
+    }
+    const double tot = block_sum<256, double>((double)acc, red);
+    if (tid == 0) partials[(size_t)d * nparts + part] = tot;
+}
+
+// G lanes cooperate on one row of C logits (G = pow2 >= min(C,64)); each lane keeps KMAX logits in registers.
+template <int G, int KMAX>
+__global__ __launch_bounds__(256) void ll_softmax_kernel(const float* __restrict__ act,
+                                                         const int64_t* __restrict__ y,
+                                                         const float* __restrict__ w, int w_is_logits, int D, int B,
+                                                         int C, float inv_batch, float* __restrict__ dact,
+                                                         float* __restrict__ ll, double* __restrict__ partials,
+                                                         int nparts) {
+    __shared__ double red[4];
+    const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const int gl = tid % G, grp = tid / G;
+    constexpr int NGROUPS = 256 / G;
+    const float wd = depth_weight(w, w_is_logits, D, d);
+    const float coef = wd * inv_batch;
+    const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
+    float acc = 0.f;
+    for (int row = part * ROWS_PER_BLOCK + grp; row < row_end; row += NGROUPS) {
+        const size_t off = ((size_t)d * B + row) * C;
+        const float* a = act + off;
+        float v[KMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int j = gl + k * G;
+            v[k] = j < C ? a[j] : -INFINITY;
+            mx = fmaxf(mx, v[k]);
+        }
+        mx = group_max<G>(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) s += (gl + k * G < C) ? expf(v[k] - mx) : 0.f;
+        s = group_sum<G>(s);
+        const float lse = mx + logf(s);
+        const int yb = (int)y[row];
+        float ay = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) ay += (gl + k * G == yb) ? v[k] : 0.f;
+        ay = group_sum<G>(ay);
+        const float row_ll = ay - lse;
+        if (gl == 0) {
+            acc += row_ll;
+            if (ll) ll[(size_t)d * B + row] = row_ll;
+        }
+        if (dact) {
+            float* g = dact + off;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int j = gl + k * G;
+                if (j < C) {
+                    const float pr = expf(v[k] - lse);
+                    g[j] = -coef * ((j == yb ? 1.f : 0.f) - pr);
+                }
+            }
+        }
+    }
+    const double tot = block_sum<256, double>((double)acc, red);
+    if (tid == 0) partials[(size_t)d * nparts + part] = tot;
+}
+
+// out[j] = sum_i in[j*n + i], fixed order; one wavefront per output
+__global__ __launch_bounds__(64) void reduce_rows_f64_kernel(const double* __restrict__ in, int n,
+                                                             double* __restrict__ out) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) s += in[(size_t)j * n + i];
+    s = wave_sum(s);
+    if (lane == 0) out[j] = s;
+}
+
+// One wavefront turns the per-depth sums into everything the objective and its backward need (fp64 inside).
+__global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __restrict__ sums, int gaussian,
+                                                            const float* __restrict__ q_logits,
+                                                            const float* __restrict__ logprior,
+                                                            const float* __restrict__ prior_ll,
+                                                            const float* __restrict__ log_std, int D, double N,
+                                                            double batch, double beta, double eps, int objective,
+                                                            float* __restrict__ res) {
+    const int lane = threadIdx.x;
+    float* joint_o = res + DUN_RES_HEADER;
+    float* w_o = joint_o + D;
+    float* dq_o = w_o + D;
+    float* post_o = dq_o + D;
+    float* llsum_o = post_o + D;
+
+    double sigma = 1.0, live = 0.0;
+    if (gaussian) {
+        const double raw = exp((double)log_std[0]);
+        // the reference clamps in fp32: compare in fp32 so the branch agrees with it at the boundary
+        live = (expf(log_std[0]) >= 1e-4f) ? 1.0 : 0.0;
+        sigma = live != 0.0 ? raw : (double)1e-4f;
+    }
+    const double inv_var = 1.0 / (sigma * sigma);
+
+    // joint and the exact marginal / posterior
+    double mx = -INFINITY;
+    for (int d = lane; d < D; d += 64) {
+        const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
+        const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
+        llsum_o[d] = (float)LL;
+        joint_o[d] = (float)J;
+        mx = fmax(mx, J + (double)logprior[d]);
+    }
+    mx = wave_max(mx);
+    double se = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
+        const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
+        se += exp(J + (double)logprior[d] - mx);
+    }
+    se = wave_sum(se);
+    const double log_marg = mx + log(se);
+
+    double qmx = -INFINITY, qs = 0.0;
+    if (objective == DUN_OBJ_VI) {
+        for (int d = lane; d < D; d += 64) qmx = fmax(qmx, (double)q_logits[d]);
+        qmx = wave_max(qmx);
+        for (int d = lane; d < D; d += 64) qs += exp((double)q_logits[d] - qmx);
+        qs = wave_sum(qs);
+    }
+    const double log_qs = log(qs);
+
+    double E = 0.0, KL = 0.0, Asum = 0.0, Csum = 0.0, dls = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
+        const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
+        const double lp = (double)logprior[d];
+        const double post = exp(J + lp - log_marg);
+        post_o[d] = (float)post;
+        double wgt = post;
+        if (objective == DUN_OBJ_VI) {
+            const double lq = (double)q_logits[d] - qmx - log_qs;
+            const double q = exp(lq);
+            const double c = fmin(fmax(q, eps), 1.0 - eps);
+            const double m = (q >= eps && q <= 1.0 - eps) ? 1.0 : 0.0;
+            E += q * J;
+            KL += c * (lq - lp);
+            Asum += m * q * (lq - lp);
+            Csum += c;
+            wgt = q;
+        }
+        w_o[d] = (float)wgt;
+        if (gaussian) dls += wgt * (sums[d] * inv_var - batch);
+    }
+    E = wave_sum(E);
+    KL = wave_sum(KL);
+    Asum = wave_sum(Asum);
+    Csum = wave_sum(Csum);
+    dls = wave_sum(dls);
+
+    for (int d = lane; d < D; d += 64) {
+        double dq = 0.0;
+        if (objective == DUN_OBJ_VI) {
+            const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
+            const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
+            const double lp = (double)logprior[d];
+            const double lq = (double)q_logits[d] - qmx - log_qs;
+            const double q = exp(lq);
+            const double c = fmin(fmax(q, eps), 1.0 - eps);
+            const double m = (q >= eps && q <= 1.0 - eps) ? 1.0 : 0.0;
+            const double dKL = m * q * (lq - lp) - q * Asum + c - q * Csum;
+            dq = -(1.0 / N) * (q * (J - E) - beta * dKL);
+        }
+        dq_o[d] = (float)dq;
+    }
+    if (lane == 0) {
+        res[DUN_RES_OBJECTIVE] = (float)(objective == DUN_OBJ_VI ? E - beta * KL : log_marg);
+        res[DUN_RES_E_LOGLIKE] = (float)E;
+        res[DUN_RES_KL] = (float)KL;
+        res[DUN_RES_LOG_MARG] = (float)log_marg;
+        res[DUN_RES_DLOG_STD] = (float)(gaussian ? -(1.0 / batch) * dls * live : 0.0);
+        res[5] = 0.f;
+        res[6] = 0.f;
+        res[7] = 0.f;
+    }
+}
+
+// ---- depth-marginal prediction ----
+template <bool VEC>
+__global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restrict__ act, const float* __restrict__ q,
+                                                            int D, int n, float* __restrict__ mean,
+                                                            float* __restrict__ std, const float* __restrict__ y,
+                                                            const float* __restrict__ log_std,
+                                                            double* __restrict__ partials, int nparts) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int idx = (blockIdx.x * 256 + tid) * 4;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool any = idx < n;
+    if (any) {
+        for (int d = 0; d < D; ++d) {
+            const float qd = q[d];
+            const float* a = act + (size_t)d * n + idx;
+            float v[4];
+            if (VEC) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(a);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (idx + e < n) ? a[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mu[e] += qd * v[e];
+                m2[e] += qd * (v[e] * v[e]);
+            }
+        }
+    }
+    float sd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sd[e] = sqrtf(m2[e] - mu[e] * mu[e]);  // NaN for a negative variance, as pow(0.5)
+    double nll = 0.0, se = 0.0;
+    if (any) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (idx + e < n) {
+                mean[idx + e] = mu[e];
+                if (std) std[idx + e] = sd[e];
+            }
+        }
+        if (partials) {
+            const float sig = fmaxf(expf(log_std[0]), 1e-4f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (idx + e < n) {
+                    const float st = sqrtf(sig * sig + sd[e] * sd[e]);
+                    const float r = y[idx + e] - mu[e];
+                    nll += (double)(LOG_SQRT_2PI_F + logf(st) + r * r / (2.f * st * st));
+                    se += (double)(r * r);
+                }
+            }
+        }
+    }
+    if (partials) {
+        const double t0 = block_sum<256, double>(nll, red);
+        const double t1 = block_sum<256, double>(se, red);
+        if (tid == 0) {
+            partials[blockIdx.x] = t0;
+            partials[nparts + blockIdx.x] = t1;
+        }
+    }
+}
+
+template <int G, int KMAX>
+__global__ __launch_bounds__(256) void predict_softmax_kernel(const float* __restrict__ act,
+                                                              const float* __restrict__ q, int D, int B, int C,
+                                                              float* __restrict__ probs,
+                                                              const int64_t* __restrict__ y,
+                                                              double* __restrict__ partials, int nparts) {
+    __shared__ double red[4];
+    const int part = blockIdx.x, tid = threadIdx.x;
+    const int gl = tid % G, grp = tid / G;
+    constexpr int NGROUPS = 256 / G;
+    const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
+    double nll = 0.0, nerr = 0.0;
+    for (int row = part * ROWS_PER_BLOCK + grp; row < row_end; row += NGROUPS) {
+        float pr[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) pr[k] = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float* a = act + ((size_t)d * B + row) * C;
+            float v[KMAX];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int j = gl + k * G;
+                v[k] = j < C ? a[j] : -INFINITY;
+                mx = fmaxf(mx, v[k]);
+            }
+            mx = group_max<G>(mx);
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                v[k] = (gl + k * G < C) ? expf(v[k] - mx) : 0.f;
+                s += v[k];
+            }
+            s = group_sum<G>(s);
+            const float sc = q[d] / s;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) pr[k] += sc * v[k];
+        }
+        float* o = probs + (size_t)row * C;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (gl + k * G < C) o[gl + k * G] = pr[k];
+        if (partials) {
+            const int yb = (int)y[row];
+            float py = 0.f, best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int j = gl + k * G;
+                if (j < C) {
+                    if (j == yb) py = pr[k];
+                    if (pr[k] > best) { best = pr[k]; bi = j; }
+                }
+            }
+            py = group_sum<G>(py);
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) {
+                const float ob = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (gl == 0) {
+                nll += (double)(-logf(py));
+                nerr += (bi != yb) ? 1.0 : 0.0;
+            }
+        }
+    }
+    if (partials) {
+        const double t0 = block_sum<256, double>(nll, red);
+        const double t1 = block_sum<256, double>(nerr, red);
+        if (tid == 0) {
+            partials[part] = t0;
+            partials[nparts + part] = t1;
+        }
+    }
+}
+
+// ---- host side ----
+static int softmax_group(int C, int* kmax) {
+    int G = 2;
+    while (G < C && G < 64) G <<= 1;
+    int k = 1;
+    while (G * k < C) k <<= 1;
+    *kmax = k;
+    return G;
+}
+
+#define DUN_SOFTMAX_DISPATCH(KERNEL, G, KM, grid, s, ...)                                             \
+    do {                                                                                              \
+        if (KM == 1) {                                                                                \
+            switch (G) {                                                                              \
+                case 2: hipLaunchKernelGGL((KERNEL<2, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;   \
+                case 4: hipLaunchKernelGGL((KERNEL<4, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;   \
+                case 8: hipLaunchKernelGGL((KERNEL<8, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break;   \
+                case 16: hipLaunchKernelGGL((KERNEL<16, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+                case 32: hipLaunchKernelGGL((KERNEL<32, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+                default: hipLaunchKernelGGL((KERNEL<64, 1>), grid, dim3(256), 0, s, __VA_ARGS__); break; \
+            }                                                                                         \
+        } else if (KM == 2) {                                                                         \
+            hipLaunchKernelGGL((KERNEL<64, 2>), grid, dim3(256), 0, s, __VA_ARGS__);                  \
+        } else if (KM == 4) {                                                                         \
+            hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(256), 0, s, __VA_ARGS__);                  \
+        } else if (KM == 8) {                                                                         \
+            hipLaunchKernelGGL((KERNEL<64, 8>), grid, dim3(256), 0, s, __VA_ARGS__);                  \
+        } else {                                                                                      \
+            hipLaunchKernelGGL((KERNEL<64, 16>), grid, dim3(256), 0, s, __VA_ARGS__);                 \
+        }                                                                                             \
+    } while (0)
+
+}  // namespace dun
+
+using namespace dun;
+
+extern "C" int dun_ll_num_partials(int B, int C) {
+    if (B <= 0) return 0;
+    return C <= 1 ? ceil_div(B, GAUSS_PER_BLOCK) : ceil_div(B, ROWS_PER_BLOCK);
+}
+
+extern "C" int dun_predict_num_partials(int n, int C) {
+    if (n <= 0) return 0;
+    return C <= 1 ? ceil_div(n, 1024) : ceil_div(n, ROWS_PER_BLOCK);
+}
+
+extern "C" int dun_ll_gauss(const float* act, const float* y, const float* log_std, const float* w, int w_is_logits,
+                            int D, int B, float inv_batch, float* dact, float* ll, double* partials,
+                            dun_stream_t stream) {
+    DUN_REQUIRE(act && y && log_std && partials, "dun_ll_gauss: null pointer");
+    DUN_REQUIRE(D > 0 && B > 0, "dun_ll_gauss: empty input D=%d B=%d", D, B);
+    DUN_REQUIRE(D <= 65535, "dun_ll_gauss: D=%d exceeds grid.y", D);
+    DUN_REQUIRE(dact == nullptr || w != nullptr, "dun_ll_gauss: dact requested without depth weights");
+    const int nparts = dun_ll_num_partials(B, 1);
+    const bool vec = (B % 4 == 0) && aligned16(act) && aligned16(y) && (!dact || aligned16(dact)) &&
+                     (!ll || aligned16(ll));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (vec)
+        hipLaunchKernelGGL(ll_gauss_kernel<true>, dim3(nparts, D), dim3(256), 0, s, act, y, log_std, w, w_is_logits, D,
+                           B, inv_batch, dact, ll, partials, nparts);
+    else
+        hipLaunchKernelGGL(ll_gauss_kernel<false>, dim3(nparts, D), dim3(256), 0, s, act, y, log_std, w, w_is_logits,
+                           D, B, inv_batch, dact, ll, partials, nparts);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+extern "C" int dun_ll_softmax(const float* act, const int64_t* y, const float* w, int w_is_logits, int D, int B, int C,
+                              float inv_batch, float* dact, float* ll, double* partials, dun_stream_t stream) {
+    DUN_REQUIRE(act && y && partials, "dun_ll_softmax: null pointer");
+    DUN_REQUIRE(D > 0 && B > 0 && C > 0, "dun_ll_softmax: empty input D=%d B=%d C=%d", D, B, C);
+    DUN_REQUIRE(D <= 65535, "dun_ll_softmax: D=%d exceeds grid.y", D);
+    DUN_REQUIRE(dact == nullptr || w != nullptr, "dun_ll_softmax: dact requested without depth weights");
+    if (C > 1024) {
+        set_error("dun_ll_softmax: C=%d classes > 1024 not implemented", C);
+        return DUN_ERR_UNSUPPORTED;
+    }
+    int km;
+    const int G = softmax_group(C, &km);
+    const int nparts = dun_ll_num_partials(B, C);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DUN_SOFTMAX_DISPATCH(ll_softmax_kernel, G, km, dim3(nparts, D), s, act, y, w, w_is_logits, D, B, C, inv_batch,
+                         dact, ll, partials, nparts);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+extern "C" int dun_ll_reduce(const double* partials, int D, int nparts, double* sums, dun_stream_t stream) {
+    DUN_REQUIRE(partials && sums, "dun_ll_reduce: null pointer");
+    DUN_REQUIRE(D > 0 && nparts > 0, "dun_ll_reduce: empty input");
+    hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(D), dim3(64), 0, static_cast<hipStream_t>(stream), partials,
+                       nparts, sums);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+extern "C" int dun_depth_finalize(const double* sums, int gaussian, const float* q_logits, const float* logprior,
+                                  const float* prior_ll, const float* log_std, int D, double N_train, double batch,
+                                  double beta, double eps, int objective, float* result, dun_stream_t stream) {
+    DUN_REQUIRE(sums && logprior && result, "dun_depth_finalize: null pointer");
+    DUN_REQUIRE(D > 0 && batch > 0 && N_train > 0, "dun_depth_finalize: bad sizes");
+    DUN_REQUIRE(objective == DUN_OBJ_VI || objective == DUN_OBJ_MLL, "dun_depth_finalize: bad objective %d", objective);
+    DUN_REQUIRE(objective != DUN_OBJ_VI || q_logits != nullptr, "dun_depth_finalize: VI needs q_logits");
+    DUN_REQUIRE(!gaussian || log_std != nullptr, "dun_depth_finalize: gaussian needs log_std");
+    hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), sums, gaussian,
+                       q_logits, logprior, prior_ll, log_std, D, N_train, batch, beta, eps, objective, result);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std,
+                                 const float* y, const float* log_std, double* partials, double* metrics,
+                                 dun_stream_t stream) {
+    DUN_REQUIRE(act && q && mean, "dun_predict_gauss: null pointer");
+    DUN_REQUIRE(D > 0 && n > 0, "dun_predict_gauss: empty input");
+    DUN_REQUIRE(metrics == nullptr || (y && log_std && partials), "dun_predict_gauss: metrics need y, log_std, partials");
+    const int nparts = dun_predict_num_partials(n, 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* part = metrics ? partials : nullptr;
+    const bool vec = (n % 4 == 0) && aligned16(act);
+    if (vec)
+        hipLaunchKernelGGL(predict_gauss_kernel<true>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
+                           log_std, part, nparts);
+    else
+        hipLaunchKernelGGL(predict_gauss_kernel<false>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
+                           log_std, part, nparts);
+    DUN_LAUNCH_CHECK();
+    if (metrics) {
+        hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);
+        DUN_LAUNCH_CHECK();
+    }
+    return DUN_OK;
+}
+
+extern "C" int dun_predict_softmax(const float* act, const float* q, int D, int B, int C, float* probs,
+                                   const int64_t* y, double* partials, double* metrics, dun_stream_t stream) {
+    DUN_REQUIRE(act && q && probs, "dun_predict_softmax: null pointer");
+    DUN_REQUIRE(D > 0 && B > 0 && C > 0, "dun_predict_softmax: empty input");
+    DUN_REQUIRE(metrics == nullptr || (y && partials), "dun_predict_softmax: metrics need y and partials");
+    if (C > 1024) {
+        set_error("dun_predict_softmax: C=%d classes > 1024 not implemented", C);
+        return DUN_ERR_UNSUPPORTED;
+    }
+    int km;
+    const int G = softmax_group(C, &km);
+    const int nparts = dun_predict_num_partials(B, C > 1 ? C : 2);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* part = metrics ? partials : nullptr;
+    DUN_SOFTMAX_DISPATCH(predict_softmax_kernel, G, km, dim3(nparts), s, act, q, D, B, C, probs, y, part, nparts);
+    DUN_LAUNCH_CHECK();
+    if (metrics) {
+        hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);
+        DUN_LAUNCH_CHECK();
+    }
+    return DUN_OK;
+}

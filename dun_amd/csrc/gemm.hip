@@ -1,0 +1,281 @@
+// fp32 MFMA GEMM for the DUN residual-MLP trunk (gfx950).
+//
+// C[M,N] = epi(sum_k A(m,k) B(k,n)) on v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), so the
+// trunk keeps the reference's fp32 numerics (north-star: 1e-5 relative) while running on the matrix cores.
+// Workgroup = 256 threads = 4 waves (2x2), tile 128x128x32, each wave a 64x64 sub-tile = 2x2 MFMA 32x32
+// accumulators.  Operand tiles are staged global -> registers -> LDS, double buffered, one barrier per K
+// tile; the register prefetch of tile t+1 is in flight while tile t is multiplied.
+//
+// Operands keep their global orientation in LDS, so no transposes are ever materialised:
+//   K-contiguous operand (x / h / dU rows, Linear weight rows): LDS [128][32+4] floats; a lane reads its
+//     four k values with one ds_read_b128 (144-B row stride: conflict-free for the 16-lane b128 groups);
+//   M/N-contiguous operand (W in dX = dU W, dU^T and H in dW = dU^T H): LDS [32][128]; a lane reads one
+//     float per MFMA with ds_read_b32, 32 consecutive lanes on 32 consecutive banks.
+// Both forms feed the MFMA with k(step s=(t,e), lane half h) = 8t + 4h + e, so any pairing is consistent.
+//
+// Epilogues (all optional, fused): + bias[n], ReLU, + R[m,n] (residual / running gradient), + U[m,:] V[:,n]
+// (the head's rank-O gradient contribution), and per-128-row-tile column sums of C and C^2 (BatchNorm
+// batch statistics, reduced later in fp64).
+#include "common.h"
+
+namespace dun {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK = BK + 4;
+constexpr int TILE_FLOATS = BM * LDK;  // 4608 >= BK*BM
+
+struct GemmP {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K, lda, ldb, ldc;
+    const float* bias;
+    int relu;
+    const float* R;
+    int ldr;
+    const float* U;
+    const float* V;
+    int O, ldv;
+    float* colstats;
+    int gridM, gridN;
+};
+
+// ---- global -> register staging of one operand tile: 4 x float4 per thread ----
+template <bool KC, bool VEC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int r0, int rows, int k0, int K,
+                                          int tid, f32x4 (&reg)[4]) {
+    if (KC) {
+        const int c4 = (tid & 7) * 4, rr = tid >> 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + rr + 32 * r, k = k0 + c4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < rows) {
+                const float* src = P + (size_t)row * ld + k;
+                if (VEC) {
+                    if (k < K) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < K) v[e] = src[e];
+                }
+            }
+            reg[r] = v;
+        }
+    } else {
+        const int c4 = (tid & 31) * 4, kk = tid >> 5;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + kk + 8 * r, row = r0 + c4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < K) {
+                const float* src = P + (size_t)k * ld + row;
+                if (VEC) {
+                    if (row < rows) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row + e < rows) v[e] = src[e];
+                }
+            }
+            reg[r] = v;
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* lds, int tid, const f32x4 (&reg)[4]) {
+    if (KC) {
+        const int c4 = (tid & 7) * 4, rr = tid >> 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(lds + (rr + 32 * r) * LDK + c4) = reg[r];
+    } else {
+        const int c4 = (tid & 31) * 4, kk = tid >> 5;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(lds + (kk + 8 * r) * BM + c4) = reg[r];
+    }
+}
+
+// fragment for MFMA steps (t, e=0..3): element e of lane (i, h) is operand[row i][k = 8t + 4h + e]
+template <bool KC>
+__device__ __forceinline__ void read_frag(const float* lds, int row, int t, int h, float (&f)[4]) {
+    if (KC) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * LDK + 8 * t + 4 * h);
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = lds[(8 * t + 4 * h + e) * BM + row];
+    }
+}
+
+template <bool A_KC, bool B_KC, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
+    // 72 KiB static LDS: [buffer][A tile | B tile]; two workgroups per CU fit in the 160 KiB
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+
+    // XCD-aware remap (bijective): the 8 XCDs take contiguous ranges of tiles so that the tiles sharing an
+    // A row-panel (all bn of one bm) hit the same L2.
+    const int nwg = p.gridM * p.gridN;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.gridN, bn = bid % p.gridN;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile<A_KC, VEC>(p.A, p.lda, m0, p.M, 0, p.K, tid, ra);
+    load_tile<B_KC, VEC>(p.B, p.ldb, n0, p.N, 0, p.K, tid, rb);
+    store_tile<A_KC>(smem, tid, ra);
+    store_tile<B_KC>(smem + TILE_FLOATS, tid, rb);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_tile<A_KC, VEC>(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid, ra);
+            load_tile<B_KC, VEC>(p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid, rb);
+        }
+        const float* a_s = smem + cur * (2 * TILE_FLOATS);
+        const float* b_s = a_s + TILE_FLOATS;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) read_frag<A_KC>(a_s, wr * 64 + mi * 32 + li, t, h, a[mi]);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) read_frag<B_KC>(b_s, wc * 64 + ni * 32 + li, t, h, b[ni]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) {
+            float* nxt = smem + (cur ^ 1) * (2 * TILE_FLOATS);
+            store_tile<A_KC>(nxt, tid, ra);
+            store_tile<B_KC>(nxt + TILE_FLOATS, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wc * 64 + ni * 32 + li;
+        const bool col_ok = col < p.N;
+        const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < p.M && col_ok) {
+                    float v = acc[mi][ni][r] + bv;
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    if (p.R != nullptr) v += p.R[(size_t)row * p.ldr + col];
+                    if (p.U != nullptr) {
+                        for (int o = 0; o < p.O; ++o) v += p.U[(size_t)row * p.O + o] * p.V[(size_t)o * p.ldv + col];
+                    }
+                    p.C[(size_t)row * p.ldc + col] = v;
+                    s1[ni] += v;
+                    s2[ni] += v * v;
+                }
+            }
+        }
+    }
+    if (p.colstats != nullptr) {
+        float* red = smem;  // all waves are past the last barrier of the main loop: LDS is free
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            s1[ni] += __shfl_xor(s1[ni], 32, 64);
+            s2[ni] += __shfl_xor(s2[ni], 32, 64);
+            if (h == 0) {
+                red[((wave * 2 + ni) * 32 + li) * 2 + 0] = s1[ni];
+                red[((wave * 2 + ni) * 32 + li) * 2 + 1] = s2[ni];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int wc2 = tid >> 6, ni2 = (tid >> 5) & 1, l2 = tid & 31, col = n0 + tid;
+            if (col < p.N) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    const int wv = w2 * 2 + wc2;
+                    t1 += red[((wv * 2 + ni2) * 32 + l2) * 2 + 0];
+                    t2 += red[((wv * 2 + ni2) * 32 + l2) * 2 + 1];
+                }
+                p.colstats[(size_t)bm * p.N + col] = t1;
+                p.colstats[(size_t)(p.gridM + bm) * p.N + col] = t2;
+            }
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_gemm(const GemmP& p, bool vec, hipStream_t s) {
+    const int grid = p.gridM * p.gridN;
+    if (vec)
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), dim3(grid), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), dim3(grid), dim3(256), 0, s, p);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
+    DUN_REQUIRE(d != nullptr, "dun_gemm_f32: null descriptor");
+    DUN_REQUIRE(d->A && d->B && d->C, "dun_gemm_f32: null operand");
+    DUN_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "dun_gemm_f32: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+    DUN_REQUIRE(d->lda >= (d->a_kcontig ? d->K : d->M), "dun_gemm_f32: lda=%d too small", d->lda);
+    DUN_REQUIRE(d->ldb >= (d->b_kcontig ? d->K : d->N), "dun_gemm_f32: ldb=%d too small", d->ldb);
+    DUN_REQUIRE(d->ldc >= d->N, "dun_gemm_f32: ldc=%d too small", d->ldc);
+    DUN_REQUIRE(d->R == nullptr || d->ldr >= d->N, "dun_gemm_f32: ldr=%d too small", d->ldr);
+    DUN_REQUIRE(d->U == nullptr || (d->V != nullptr && d->O > 0 && d->ldv >= d->N),
+                "dun_gemm_f32: rank update needs V, O>0 and ldv>=N");
+    GemmP p;
+    p.A = d->A; p.B = d->B; p.C = d->C;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+    p.bias = d->bias; p.relu = d->relu;
+    p.R = d->R; p.ldr = d->ldr;
+    p.U = d->U; p.V = d->V; p.O = d->O; p.ldv = d->ldv;
+    p.colstats = d->colstats;
+    p.gridM = ceil_div(d->M, BM);
+    p.gridN = ceil_div(d->N, BN);
+    DUN_REQUIRE((long long)p.gridM * p.gridN < (1ll << 31), "dun_gemm_f32: grid too large");
+    // float4 staging needs 16-byte aligned rows on both operands; anything else takes the scalar loads
+    const bool va = aligned16(d->A) && d->lda % 4 == 0 && (d->a_kcontig ? d->K % 4 == 0 : d->M % 4 == 0);
+    const bool vb = aligned16(d->B) && d->ldb % 4 == 0 && (d->b_kcontig ? d->K % 4 == 0 : d->N % 4 == 0);
+    const bool vec = va && vb;
+    if (d->a_kcontig) {
+        if (d->b_kcontig) return launch_gemm<true, true>(p, vec, s);
+        return launch_gemm<true, false>(p, vec, s);
+    }
+    if (d->b_kcontig) return launch_gemm<false, true>(p, vec, s);
+    return launch_gemm<false, false>(p, vec, s);
+}
+
+}  // namespace dun
+
+extern "C" int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream) {
+    return dun::gemm_f32(desc, static_cast<hipStream_t>(stream));
+}

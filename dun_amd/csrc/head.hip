@@ -1,0 +1,244 @@
+// Shared output head over all depths as one batched contraction (gfx950).
+//
+// The reference applies ONE Linear(width, O) to the hidden state of every depth (FC) or to the pooled
+// features of every exit (image DUNs).  Here the D*B rows are one HBM stream: a wavefront takes a row,
+// lanes take 16-byte column chunks, O accumulators per lane, one butterfly reduction per output.  With O
+// small (1 for regression, 10 for MNIST/CIFAR) this is bandwidth bound: 4*K bytes per row read once.
+// Backward streams the same rows once more: thread-owned column chunks accumulate dw over 1024-row slabs
+// (fixed-order LDS combine, then an fp64 reduction over slabs: reproducible), db rides along, and the
+// optional dH = dact w is written in the same pass for callers that need it (the image trunk's autograd).
+#include "common.h"
+
+namespace dun {
+
+constexpr int HSLAB = 1024;  // rows per dw partial
+constexpr int HCX = 64, HRY = 4;
+
+template <int OC, bool VEC>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int rows, int K, int O,
+                                                       float* __restrict__ act) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int row = wave; row < rows; row += nwaves) {
+        const float* h = H + (size_t)row * K;
+        for (int o0 = 0; o0 < O; o0 += OC) {
+            float acc[OC];
+#pragma unroll
+            for (int j = 0; j < OC; ++j) acc[j] = 0.f;
+            if (VEC) {
+                for (int k = lane * 4; k < K; k += 256) {
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + k);
+#pragma unroll
+                    for (int j = 0; j < OC; ++j) {
+                        if (o0 + j < O) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)(o0 + j) * K + k);
+                            acc[j] += (hv[0] * wv[0] + hv[1] * wv[1]) + (hv[2] * wv[2] + hv[3] * wv[3]);
+                        }
+                    }
+                }
+            } else {
+                for (int k = lane; k < K; k += 64) {
+                    const float hv = h[k];
+#pragma unroll
+                    for (int j = 0; j < OC; ++j)
+                        if (o0 + j < O) acc[j] += hv * w[(size_t)(o0 + j) * K + k];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < OC; ++j) {
+                const float t = wave_sum(acc[j]);
+                if (lane == 0 && o0 + j < O) act[(size_t)row * O + o0 + j] = t + b[o0 + j];
+            }
+        }
+    }
+}
+
+// One workgroup: 64 column-chunks x 4 row lanes over a slab of HSLAB rows.  o0: first output of this launch.
+template <int OC, int VW>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
+                                                       const float* __restrict__ dact, int rows, int K, int O, int o0,
+                                                       float* __restrict__ part_dw, float* __restrict__ part_db,
+                                                       float* __restrict__ dH, int nslab) {
+    __shared__ float red[HRY][HCX * VW];
+    const int tx = threadIdx.x & (HCX - 1), ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * HCX + tx) * VW;
+    const int slab = blockIdx.y;
+    const bool live = c < K;
+    float acc[OC][VW], wv[OC][VW], sdb[OC];
+#pragma unroll
+    for (int j = 0; j < OC; ++j) {
+        sdb[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            acc[j][e] = 0.f;
+            wv[j][e] = (dH && live && o0 + j < O) ? w[(size_t)(o0 + j) * K + c + e] : 0.f;
+        }
+    }
+    const int r1 = min(rows, (slab + 1) * HSLAB);
+    if (live) {
+        for (int r = slab * HSLAB + ty; r < r1; r += HRY) {
+            float hv[VW];
+            if (VW == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(H + (size_t)r * K + c);
+                hv[0] = t[0]; hv[1] = t[1]; hv[2] = t[2]; hv[3] = t[3];
+            } else {
+                hv[0] = H[(size_t)r * K + c];
+            }
+            float dh[VW];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) dh[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < OC; ++j) {
+                if (o0 + j < O) {
+                    const float d = dact[(size_t)r * O + o0 + j];
+                    sdb[j] += d;
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) {
+                        acc[j][e] += d * hv[e];
+                        dh[e] += d * wv[j][e];
+                    }
+                }
+            }
+            if (dH) {
+                float* o = dH + (size_t)r * K + c;
+                if (VW == 4) {
+                    f32x4 t = {dh[0], dh[1], dh[2], dh[3]};
+                    if (o0 != 0) t += *reinterpret_cast<const f32x4*>(o);
+                    *reinterpret_cast<f32x4*>(o) = t;
+                } else {
+                    o[0] = (o0 == 0 ? 0.f : o[0]) + dh[0];
+                }
+            }
+        }
+    }
+    // fixed-order combine of the 4 row lanes, one output at a time
+#pragma unroll
+    for (int j = 0; j < OC; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VW; ++e) red[ty][tx * VW + e] = acc[j][e];
+        __syncthreads();
+        if (ty == 0 && live && o0 + j < O) {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const int i = tx * VW + e;
+                part_dw[((size_t)slab * O + o0 + j) * K + c + e] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+            }
+        }
+    }
+    // db: every column thread saw the same dact values; the tx == 0 threads of the first column block own it
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < OC; ++j) {
+            __syncthreads();
+            if (tx == 0) red[ty][0] = sdb[j];
+            __syncthreads();
+            if (threadIdx.x == 0 && o0 + j < O)
+                part_db[(size_t)slab * O + o0 + j] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        }
+    }
+}
+
+// out[c] = sum_p partials[p][c] in fp64, fixed order (64 columns x 4 partial lanes per workgroup)
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ partials, int P, size_t n,
+                                                          float* __restrict__ out) {
+    __shared__ double red[HRY][HCX];
+    const int tx = threadIdx.x & (HCX - 1), ty = threadIdx.x >> 6;
+    const size_t c = (size_t)blockIdx.x * HCX + tx;
+    double s = 0.0;
+    if (c < n)
+        for (int p = ty; p < P; p += HRY) s += (double)partials[(size_t)p * n + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < n) out[c] = (float)((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+}
+
+static int pick_oc(int O) {
+    if (O <= 1) return 1;
+    if (O <= 2) return 2;
+    if (O <= 4) return 4;
+    if (O <= 8) return 8;
+    return 16;
+}
+
+int head_forward(const float* H, const float* w, const float* b, int rows, int K, int O, float* act, hipStream_t s) {
+    DUN_REQUIRE(H && w && b && act, "dun_head_forward: null pointer");
+    DUN_REQUIRE(rows > 0 && K > 0 && O > 0, "dun_head_forward: empty input rows=%d K=%d O=%d", rows, K, O);
+    const bool vec = K % 4 == 0 && aligned16(H) && aligned16(w);
+    int grid = ceil_div(rows, 4);
+    if (grid > 4096) grid = 4096;
+#define HF(OC)                                                                                              \
+    do {                                                                                                    \
+        if (vec) hipLaunchKernelGGL((head_fwd_kernel<OC, true>), dim3(grid), dim3(256), 0, s, H, w, b, rows, K, O, act); \
+        else hipLaunchKernelGGL((head_fwd_kernel<OC, false>), dim3(grid), dim3(256), 0, s, H, w, b, rows, K, O, act);    \
+    } while (0)
+    switch (pick_oc(O)) {
+        case 1: HF(1); break;
+        case 2: HF(2); break;
+        case 4: HF(4); break;
+        case 8: HF(8); break;
+        default: HF(16); break;
+    }
+#undef HF
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+size_t head_backward_ws(int rows, int K, int O) {
+    const size_t nslab = (size_t)ceil_div(rows, HSLAB);
+    return nslab * (size_t)O * (size_t)K + nslab * (size_t)O + 64;
+}
+
+int head_backward(const float* H, const float* w, const float* dact, int rows, int K, int O, float* dw, float* db,
+                  float* dH, float* ws, size_t ws_floats, hipStream_t s) {
+    DUN_REQUIRE(H && w && dact && dw && db && ws, "dun_head_backward: null pointer");
+    DUN_REQUIRE(rows > 0 && K > 0 && O > 0, "dun_head_backward: empty input rows=%d K=%d O=%d", rows, K, O);
+    DUN_REQUIRE(ws_floats >= head_backward_ws(rows, K, O), "dun_head_backward: workspace too small");
+    const int nslab = ceil_div(rows, HSLAB);
+    float* part_dw = ws;
+    float* part_db = ws + (size_t)nslab * O * K;
+    const bool vec = K % 4 == 0 && aligned16(H) && aligned16(w) && (!dH || aligned16(dH));
+    const int oc = pick_oc(O);
+    for (int o0 = 0; o0 < O; o0 += oc) {
+#define HB(OC)                                                                                                   \
+    do {                                                                                                         \
+        if (vec) hipLaunchKernelGGL((head_bwd_kernel<OC, 4>), dim3(ceil_div(K, HCX * 4), nslab), dim3(256), 0, s, H, w, \
+                                    dact, rows, K, O, o0, part_dw, part_db, dH, nslab);                          \
+        else hipLaunchKernelGGL((head_bwd_kernel<OC, 1>), dim3(ceil_div(K, HCX), nslab), dim3(256), 0, s, H, w, dact,   \
+                                rows, K, O, o0, part_dw, part_db, dH, nslab);                                    \
+    } while (0)
+        switch (oc) {
+            case 1: HB(1); break;
+            case 2: HB(2); break;
+            case 4: HB(4); break;
+            case 8: HB(8); break;
+            default: HB(16); break;
+        }
+#undef HB
+        DUN_LAUNCH_CHECK();
+    }
+    const size_t n = (size_t)O * K;
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((n + HCX - 1) / HCX)), dim3(256), 0, s, part_dw, nslab, n, dw);
+    DUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((O + HCX - 1) / HCX)), dim3(256), 0, s, part_db, nslab,
+                       (size_t)O, db);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+}  // namespace dun
+
+extern "C" int dun_head_forward(const float* H, const float* w, const float* b, int rows, int K, int O, float* act,
+                                dun_stream_t stream) {
+    return dun::head_forward(H, w, b, rows, K, O, act, static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t dun_head_backward_workspace_floats(int rows, int K, int O) {
+    return dun::head_backward_ws(rows, K, O);
+}
+
+extern "C" int dun_head_backward(const float* H, const float* w, const float* dact, int rows, int K, int O, float* dw,
+                                 float* db, float* dH, float* ws, size_t ws_floats, dun_stream_t stream) {
+    return dun::head_backward(H, w, dact, rows, K, O, dw, db, dH, ws, ws_floats, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,591 @@
+// Residual-MLP trunk of a DUN on device (gfx950): "forward_get_acts" and its hand-derived backward.
+//
+// Per block i (src/DUN/layers.py:38-42 in the reference):  u = h_i W_i^T + b_i ; z = ReLU(u) ;
+// h_{i+1} = [h_i +] gamma_i * (z - mean_i) * rstd_i + beta_i, BatchNorm1d statistics over the batch.
+//   forward : MFMA GEMM with bias+ReLU epilogue that also emits per-128-row column sums of z and z^2
+//             -> fp64 reduction of those partials -> (all-reduce point for a sharded batch)
+//             -> statistics/running-stat update -> one fused normalise+affine+residual pass.
+//   backward: column reductions sum_b g, sum_b g*xhat -> (all-reduce point) -> fused BN+ReLU backward
+//             producing dU and the bias-gradient partials -> dW = dU^T H_i and g <- [g +] dU W_i (+ the shared
+//             head's rank-O term dact_i w_out folded into that epilogue, so no dH tensor is ever written).
+// Hidden states of all depths live in one [D,B,W] buffer: the head reads it as one batched contraction.
+#include <math.h>
+
+#include "common.h"
+
+namespace dun {
+
+int gemm_f32(const dun_gemm_desc* d, hipStream_t s);
+int head_forward(const float* H, const float* w, const float* b, int rows, int K, int O, float* act, hipStream_t s);
+int head_backward(const float* H, const float* w, const float* dact, int rows, int K, int O, float* dw, float* db,
+                  float* dH, float* ws, size_t ws_floats, hipStream_t s);
+size_t head_backward_ws(int rows, int K, int O);
+
+constexpr int SLAB = 128;  // rows per column-reduction partial (same as the GEMM tile height)
+constexpr int CX = 64;     // threads across columns in the elementwise / column kernels
+constexpr int RY = 4;      // row lanes per workgroup
+
+template <int VW>
+struct Vec;
+template <>
+struct Vec<4> {
+    typedef f32x4 T;
+    static __device__ __forceinline__ T load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store(float* p, T v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ float get(const T& v, int e) { return v[e]; }
+    static __device__ __forceinline__ void set(T& v, int e, float x) { v[e] = x; }
+};
+template <>
+struct Vec<1> {
+    typedef float T;
+    static __device__ __forceinline__ T load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, T v) { *p = v; }
+    static __device__ __forceinline__ float get(const T& v, int) { return v; }
+    static __device__ __forceinline__ void set(T& v, int, float x) { v = x; }
+};
+
+// out_d[a][c] = sum_p partials[a][p][c] (fp64, fixed order); optional float copies per array.
+// workgroup = 64 columns x 4 partial-lanes.
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ partials, int P, int W,
+                                                          double* __restrict__ out_d, float* __restrict__ out_f0,
+                                                          float* __restrict__ out_f1) {
+    __shared__ double red[RY][CX];
+    const int tx = threadIdx.x & (CX - 1), ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * CX + tx, a = blockIdx.y;
+    double s = 0.0;
+    if (c < W) {
+        const float* src = partials + (size_t)a * P * W + c;
+        for (int p = ty; p < P; p += RY) s += (double)src[(size_t)p * W];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < W) {
+        const double t = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (out_d) out_d[(size_t)a * W + c] = t;
+        float* of = a == 0 ? out_f0 : out_f1;
+        if (of) of[c] = (float)t;
+    }
+}
+
+// batch statistics from the (possibly all-reduced) fp64 sums; running stats as nn.BatchNorm1d (unbiased var)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums, int W, double count,
+                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= W) return;
+    const double m = sums[c] / count;
+    double var = sums[W + c] / count - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const double unbiased = var * (count / (count - 1.0));
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+}
+
+// h_out = [h_in +] gamma * (z - mean) * rstd + beta.  stat_is_var: `rstd` holds a variance (eval mode).
+template <int VW>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ Z, const float* __restrict__ Hin,
+                                                       float* __restrict__ Hout, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int stat_is_var, float eps,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int B, int W, int residual,
+                                                       int rows_per_block) {
+    typedef Vec<VW> V;
+    const int tx = threadIdx.x & (CX - 1), ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * CX + tx) * VW;
+    if (c >= W) return;
+    float sc[VW], sh[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+        const float rs = stat_is_var ? 1.f / sqrtf(rstd[c + e] + eps) : rstd[c + e];
+        sc[e] = gamma[c + e] * rs;
+        sh[e] = beta[c + e] - mean[c + e] * sc[e];
+    }
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(B, r0 + rows_per_block);
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += RY) {
+        const size_t off = (size_t)r * W + c;
+        typename V::T z = V::load(Z + off), o;
+        if (residual) {
+            typename V::T hi = V::load(Hin + off);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) V::set(o, e, V::get(hi, e) + (V::get(z, e) * sc[e] + sh[e]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < VW; ++e) V::set(o, e, V::get(z, e) * sc[e] + sh[e]);
+        }
+        V::store(Hout + off, o);
+    }
+}
+
+// per-slab column sums of g and g*xhat (xhat = (z-mean)*rstd): partials [2][P][W]
+template <int VW>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ Z,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int B, int W, int P,
+                                                            float* __restrict__ partials) {
+    typedef Vec<VW> V;
+    __shared__ float red[2][RY][CX * VW];
+    const int tx = threadIdx.x & (CX - 1), ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * CX + tx) * VW;
+    const int slab = blockIdx.y;
+    float s0[VW], s1[VW], mu[VW], rs[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { s0[e] = 0.f; s1[e] = 0.f; mu[e] = 0.f; rs[e] = 0.f; }
+    if (c < W) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { mu[e] = mean[c + e]; rs[e] = rstd[c + e]; }
+        const int r1 = min(B, (slab + 1) * SLAB);
+#pragma unroll 4
+        for (int r = slab * SLAB + ty; r < r1; r += RY) {
+            const size_t off = (size_t)r * W + c;
+            const typename V::T g = V::load(G + off), z = V::load(Z + off);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const float ge = V::get(g, e);
+                s0[e] += ge;
+                s1[e] += ge * ((V::get(z, e) - mu[e]) * rs[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+        red[0][ty][tx * VW + e] = s0[e];
+        red[1][ty][tx * VW + e] = s1[e];
+    }
+    __syncthreads();
+    if (ty == 0 && c < W) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const int i = tx * VW + e;
+            partials[(size_t)slab * W + c + e] = (red[0][0][i] + red[0][1][i]) + (red[0][2][i] + red[0][3][i]);
+            partials[(size_t)(P + slab) * W + c + e] = (red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i]);
+        }
+    }
+}
+
+// dU = (z > 0) * gamma * rstd * (g - sum_g/count - xhat * sum_gx/count); per-slab column sums of dU -> partials[P][W]
+template <int VW>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ Z,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const double* __restrict__ sums, double count, int B,
+                                                           int W, float* __restrict__ dU,
+                                                           float* __restrict__ partials) {
+    typedef Vec<VW> V;
+    __shared__ float red[RY][CX * VW];
+    const int tx = threadIdx.x & (CX - 1), ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * CX + tx) * VW;
+    const int slab = blockIdx.y;
+    float acc[VW], mu[VW], rs[VW], k0[VW], mg[VW], mgx[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { acc[e] = 0.f; mu[e] = rs[e] = k0[e] = mg[e] = mgx[e] = 0.f; }
+    if (c < W) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            mu[e] = mean[c + e];
+            rs[e] = rstd[c + e];
+            k0[e] = gamma[c + e] * rs[e];
+            mg[e] = (float)(sums[c + e] / count);
+            mgx[e] = (float)(sums[W + c + e] / count);
+        }
+        const int r1 = min(B, (slab + 1) * SLAB);
+#pragma unroll 4
+        for (int r = slab * SLAB + ty; r < r1; r += RY) {
+            const size_t off = (size_t)r * W + c;
+            const typename V::T g = V::load(G + off), z = V::load(Z + off);
+            typename V::T o;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const float ze = V::get(z, e);
+                const float xh = (ze - mu[e]) * rs[e];
+                const float du = ze > 0.f ? k0[e] * (V::get(g, e) - mg[e] - xh * mgx[e]) : 0.f;
+                V::set(o, e, du);
+                acc[e] += du;
+            }
+            V::store(dU + off, o);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) red[ty][tx * VW + e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && c < W) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const int i = tx * VW + e;
+            partials[(size_t)slab * W + c + e] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        }
+    }
+}
+
+// per-slab column sums of X [B,W] -> partials [P][W]
+template <int VW>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int B, int W,
+                                                     float* __restrict__ partials) {
+    typedef Vec<VW> V;
+    __shared__ float red[RY][CX * VW];
+    const int tx = threadIdx.x & (CX - 1), ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * CX + tx) * VW;
+    const int slab = blockIdx.y;
+    float acc[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) acc[e] = 0.f;
+    if (c < W) {
+        const int r1 = min(B, (slab + 1) * SLAB);
+#pragma unroll 4
+        for (int r = slab * SLAB + ty; r < r1; r += RY) {
+            const typename V::T x = V::load(X + (size_t)r * W + c);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) acc[e] += V::get(x, e);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VW; ++e) red[ty][tx * VW + e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && c < W) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const int i = tx * VW + e;
+            partials[(size_t)slab * W + c + e] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        }
+    }
+}
+
+// G[m,n] = sum_o dact[m,o] * w_out[o,n]: the deepest exit's contribution starts the running gradient
+__global__ __launch_bounds__(256) void rank_init_kernel(float* __restrict__ G, const float* __restrict__ dact,
+                                                        const float* __restrict__ w_out, int B, int W, int O) {
+    const size_t n = (size_t)B * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / W), c = (int)(i % W);
+        float v = 0.f;
+        for (int o = 0; o < O; ++o) v += dact[(size_t)m * O + o] * w_out[(size_t)o * W + c];
+        G[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, size_t n, float lr, float momentum,
+                                                  float wd) {
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 bv = reinterpret_cast<f32x4*>(buf)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] + wd * pv[e];
+            bv[e] = momentum * bv[e] + ge;
+            pv[e] -= lr * bv[e];
+        }
+        reinterpret_cast<f32x4*>(buf)[i] = bv;
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+    }
+    const size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float ge = g[i] + wd * p[i];
+        const float b = momentum * buf[i] + ge;
+        buf[i] = b;
+        p[i] -= lr * b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------------------
+static inline int num_slabs(int B) { return ceil_div(B, SLAB); }
+static inline bool vec4_ok(int W, const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return W % 4 == 0 && aligned16(a) && (!b || aligned16(b)) && (!c || aligned16(c));
+}
+
+static int check_ctx(const dun_fc_ctx* c, const char* who) {
+    DUN_REQUIRE(c != nullptr, "%s: null context", who);
+    DUN_REQUIRE(c->B > 0 && c->din > 0 && c->W > 0 && c->O > 0 && c->L >= 0, "%s: bad sizes B=%d din=%d W=%d O=%d L=%d",
+                who, c->B, c->din, c->W, c->O, c->L);
+    DUN_REQUIRE(c->depth >= 0 && c->depth <= c->L, "%s: depth=%d outside [0,%d]", who, c->depth, c->L);
+    DUN_REQUIRE(c->p.w_in && c->p.b_in && c->p.w_out && c->p.b_out, "%s: null input/output layer parameters", who);
+    DUN_REQUIRE(c->L == 0 || (c->p.w && c->p.b && c->p.gamma && c->p.beta && c->running_mean && c->running_var),
+                "%s: null block parameters", who);
+    DUN_REQUIRE(c->x && c->H && c->act, "%s: null x/H/act", who);
+    DUN_REQUIRE(c->depth == 0 || c->Z, "%s: null Z", who);
+    DUN_REQUIRE(c->ws && c->ws_floats >= dun_fc_workspace_floats(c->B, c->din, c->W, c->O, c->L),
+                "%s: workspace too small", who);
+    DUN_REQUIRE(!c->train || c->depth == 0 || (c->bn_mean && c->bn_rstd && c->bn_sums), "%s: train mode needs bn_mean/bn_rstd/bn_sums", who);
+    return DUN_OK;
+}
+
+static int check_block(const dun_fc_ctx* c, int i, const char* who) {
+    int rc = check_ctx(c, who);
+    if (rc) return rc;
+    DUN_REQUIRE(i >= 0 && i < c->depth, "%s: block %d outside [0,%d)", who, i, c->depth);
+    return DUN_OK;
+}
+
+static inline float* Hd(const dun_fc_ctx* c, int d) { return c->H + (size_t)d * c->B * c->W; }
+static inline float* Zd(const dun_fc_ctx* c, int i) { return c->train ? c->Z + (size_t)i * c->B * c->W : c->Z; }
+
+static int input_layer(const dun_fc_ctx* c, hipStream_t s) {
+    dun_gemm_desc g;
+    memset(&g, 0, sizeof(g));
+    g.A = c->x; g.lda = c->din; g.a_kcontig = 1;
+    g.B = c->p.w_in; g.ldb = c->din; g.b_kcontig = 1;
+    g.C = Hd(c, 0); g.ldc = c->W;
+    g.M = c->B; g.N = c->W; g.K = c->din;
+    g.bias = c->p.b_in;
+    return gemm_f32(&g, s);
+}
+
+static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s) {
+    const int W = c->W, P = num_slabs(c->B);
+    dun_gemm_desc g;
+    memset(&g, 0, sizeof(g));
+    g.A = Hd(c, i); g.lda = W; g.a_kcontig = 1;
+    g.B = c->p.w + (size_t)i * W * W; g.ldb = W; g.b_kcontig = 1;
+    g.C = Zd(c, i); g.ldc = W;
+    g.M = c->B; g.N = W; g.K = W;
+    g.bias = c->p.b + (size_t)i * W;
+    g.relu = 1;
+    g.colstats = c->train ? c->ws : nullptr;
+    int rc = gemm_f32(&g, s);
+    if (rc) return rc;
+    if (c->train) {
+        hipLaunchKernelGGL(reduce_cols_kernel, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, c->ws, P, W, c->bn_sums,
+                           (float*)nullptr, (float*)nullptr);
+        DUN_LAUNCH_CHECK();
+    }
+    return DUN_OK;
+}
+
+static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s) {
+    const int W = c->W, B = c->B;
+    const float* mean;
+    const float* stat;
+    int is_var;
+    if (c->train) {
+        DUN_REQUIRE(global_batch > 1.0, "dun_fc_block_norm: BatchNorm in train mode needs more than 1 row (got %g)",
+                    global_batch);
+        float* m = c->bn_mean + (size_t)i * W;
+        float* r = c->bn_rstd + (size_t)i * W;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(W, 256)), dim3(256), 0, s, c->bn_sums, W, global_batch,
+                           c->bn_eps, c->bn_momentum, m, r, c->running_mean + (size_t)i * W,
+                           c->running_var + (size_t)i * W);
+        DUN_LAUNCH_CHECK();
+        mean = m; stat = r; is_var = 0;
+    } else {
+        mean = c->running_mean + (size_t)i * W;
+        stat = c->running_var + (size_t)i * W;
+        is_var = 1;
+    }
+    const float* Z = Zd(c, i);
+    const float* hin = Hd(c, i);
+    float* hout = Hd(c, i + 1);
+    const float* gamma = c->p.gamma + (size_t)i * W;
+    const float* beta = c->p.beta + (size_t)i * W;
+    const int rpb = 32;
+    if (vec4_ok(W, Z, hin, hout)) {
+        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ceil_div(W, CX * 4), ceil_div(B, rpb)), dim3(256), 0, s, Z, hin, hout,
+                           mean, stat, is_var, c->bn_eps, gamma, beta, B, W, c->residual, rpb);
+    } else {
+        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ceil_div(W, CX), ceil_div(B, rpb)), dim3(256), 0, s, Z, hin, hout,
+                           mean, stat, is_var, c->bn_eps, gamma, beta, B, W, c->residual, rpb);
+    }
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+static int head(const dun_fc_ctx* c, hipStream_t s) {
+    return head_forward(c->H, c->p.w_out, c->p.b_out, (c->depth + 1) * c->B, c->W, c->O, c->act, s);
+}
+
+static int check_bwd(const dun_fc_ctx* c, const char* who) {
+    int rc = check_ctx(c, who);
+    if (rc) return rc;
+    DUN_REQUIRE(c->train, "%s: backward needs the buffers of a train-mode forward", who);
+    DUN_REQUIRE(c->depth == c->L, "%s: backward through a truncated forward (depth=%d < L=%d) is not supported", who,
+                c->depth, c->L);
+    DUN_REQUIRE(c->dact && c->G, "%s: null dact/G", who);
+    DUN_REQUIRE(c->L == 0 || c->dU, "%s: null dU", who);
+    DUN_REQUIRE(c->g.w_in && c->g.b_in && c->g.w_out && c->g.b_out, "%s: null gradient outputs", who);
+    DUN_REQUIRE(c->L == 0 || (c->g.w && c->g.b && c->g.gamma && c->g.beta), "%s: null block gradient outputs", who);
+    return DUN_OK;
+}
+
+static int bwd_begin(const dun_fc_ctx* c, hipStream_t s) {
+    const int rows = (c->depth + 1) * c->B;
+    int rc = head_backward(c->H, c->p.w_out, c->dact, rows, c->W, c->O, c->g.w_out, c->g.b_out, nullptr, c->ws,
+                           c->ws_floats, s);
+    if (rc) return rc;
+    const size_t n = (size_t)c->B * c->W;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(rank_init_kernel, dim3(grid), dim3(256), 0, s, c->G, c->dact + (size_t)c->depth * c->B * c->O,
+                       c->p.w_out, c->B, c->W, c->O);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
+    const int W = c->W, B = c->B, P = num_slabs(B);
+    const float* Z = Zd(c, i);
+    const float* mean = c->bn_mean + (size_t)i * W;
+    const float* rstd = c->bn_rstd + (size_t)i * W;
+    if (vec4_ok(W, c->G, Z))
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean, rstd, B,
+                           W, P, c->ws);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, Z, mean, rstd, B, W,
+                           P, c->ws);
+    DUN_LAUNCH_CHECK();
+    // local sums are this rank's dbeta / dgamma; the fp64 copy is what a sharded job all-reduces
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, c->ws, P, W, c->bn_sums,
+                       c->g.beta + (size_t)i * W, c->g.gamma + (size_t)i * W);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s) {
+    const int W = c->W, B = c->B, P = num_slabs(B);
+    const float* Z = Zd(c, i);
+    const float* mean = c->bn_mean + (size_t)i * W;
+    const float* rstd = c->bn_rstd + (size_t)i * W;
+    const float* gamma = c->p.gamma + (size_t)i * W;
+    if (vec4_ok(W, c->G, Z, c->dU))
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean, rstd,
+                           gamma, c->bn_sums, global_batch, B, W, c->dU, c->ws);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, Z, mean, rstd, gamma,
+                           c->bn_sums, global_batch, B, W, c->dU, c->ws);
+    DUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W, (double*)nullptr,
+                       c->g.b + (size_t)i * W, (float*)nullptr);
+    DUN_LAUNCH_CHECK();
+    // dW_i[n_out, k_in] = sum_b dU[b, n_out] * H_i[b, k_in]
+    dun_gemm_desc g;
+    memset(&g, 0, sizeof(g));
+    g.A = c->dU; g.lda = W; g.a_kcontig = 0;
+    g.B = Hd(c, i); g.ldb = W; g.b_kcontig = 0;
+    g.C = c->g.w + (size_t)i * W * W; g.ldc = W;
+    g.M = W; g.N = W; g.K = B;
+    int rc = gemm_f32(&g, s);
+    if (rc) return rc;
+    // g <- [g +] dU W_i + dact_i w_out   (in place: every element is read and written by its own thread)
+    memset(&g, 0, sizeof(g));
+    g.A = c->dU; g.lda = W; g.a_kcontig = 1;
+    g.B = c->p.w + (size_t)i * W * W; g.ldb = W; g.b_kcontig = 0;
+    g.C = c->G; g.ldc = W;
+    g.M = B; g.N = W; g.K = W;
+    if (c->residual) { g.R = c->G; g.ldr = W; }
+    g.U = c->dact + (size_t)i * B * c->O; g.V = c->p.w_out; g.O = c->O; g.ldv = W;
+    return gemm_f32(&g, s);
+}
+
+static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
+    const int W = c->W, B = c->B, P = num_slabs(B);
+    // dW_in[n_out, k] = sum_b G[b, n_out] * x[b, k]
+    dun_gemm_desc g;
+    memset(&g, 0, sizeof(g));
+    g.A = c->G; g.lda = W; g.a_kcontig = 0;
+    g.B = c->x; g.ldb = c->din; g.b_kcontig = 0;
+    g.C = c->g.w_in; g.ldc = c->din;
+    g.M = W; g.N = c->din; g.K = B;
+    int rc = gemm_f32(&g, s);
+    if (rc) return rc;
+    if (vec4_ok(W, c->G))
+        hipLaunchKernelGGL(colsum_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, B, W, c->ws);
+    else
+        hipLaunchKernelGGL(colsum_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, B, W, c->ws);
+    DUN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W, (double*)nullptr,
+                       c->g.b_in, (float*)nullptr);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+}  // namespace dun
+
+using namespace dun;
+
+extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
+    (void)din;
+    const size_t P = (size_t)num_slabs(B);
+    const size_t cols = 2 * P * (size_t)W;
+    const size_t hb = head_backward_ws((L + 1) * B, W, O);
+    return (cols > hb ? cols : hb) + 64;
+}
+
+#define STREAM static_cast<hipStream_t>(stream)
+
+extern "C" int dun_fc_input_layer(const dun_fc_ctx* c, dun_stream_t stream) {
+    int rc = check_ctx(c, "dun_fc_input_layer");
+    return rc ? rc : input_layer(c, STREAM);
+}
+extern "C" int dun_fc_block_linear(const dun_fc_ctx* c, int i, dun_stream_t stream) {
+    int rc = check_block(c, i, "dun_fc_block_linear");
+    return rc ? rc : block_linear(c, i, STREAM);
+}
+extern "C" int dun_fc_block_norm(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream) {
+    int rc = check_block(c, i, "dun_fc_block_norm");
+    return rc ? rc : block_norm(c, i, global_batch, STREAM);
+}
+extern "C" int dun_fc_head(const dun_fc_ctx* c, dun_stream_t stream) {
+    int rc = check_ctx(c, "dun_fc_head");
+    return rc ? rc : head(c, STREAM);
+}
+extern "C" int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream) {
+    int rc = check_ctx(c, "dun_fc_forward");
+    if (rc) return rc;
+    if ((rc = input_layer(c, STREAM))) return rc;
+    for (int i = 0; i < c->depth; ++i) {
+        if ((rc = block_linear(c, i, STREAM))) return rc;
+        if ((rc = block_norm(c, i, (double)c->B, STREAM))) return rc;
+    }
+    return head(c, STREAM);
+}
+
+extern "C" int dun_fc_bwd_begin(const dun_fc_ctx* c, dun_stream_t stream) {
+    int rc = check_bwd(c, "dun_fc_bwd_begin");
+    return rc ? rc : bwd_begin(c, STREAM);
+}
+extern "C" int dun_fc_bwd_block_reduce(const dun_fc_ctx* c, int i, dun_stream_t stream) {
+    int rc = check_bwd(c, "dun_fc_bwd_block_reduce");
+    if (rc) return rc;
+    DUN_REQUIRE(i >= 0 && i < c->L, "dun_fc_bwd_block_reduce: block %d outside [0,%d)", i, c->L);
+    return bwd_block_reduce(c, i, STREAM);
+}
+extern "C" int dun_fc_bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream) {
+    int rc = check_bwd(c, "dun_fc_bwd_block_apply");
+    if (rc) return rc;
+    DUN_REQUIRE(i >= 0 && i < c->L, "dun_fc_bwd_block_apply: block %d outside [0,%d)", i, c->L);
+    return bwd_block_apply(c, i, global_batch, STREAM);
+}
+extern "C" int dun_fc_bwd_end(const dun_fc_ctx* c, dun_stream_t stream) {
+    int rc = check_bwd(c, "dun_fc_bwd_end");
+    return rc ? rc : bwd_end(c, STREAM);
+}
+extern "C" int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream) {
+    int rc = check_bwd(c, "dun_fc_backward");
+    if (rc) return rc;
+    if ((rc = bwd_begin(c, STREAM))) return rc;
+    for (int i = c->L - 1; i >= 0; --i) {
+        if ((rc = bwd_block_reduce(c, i, STREAM))) return rc;
+        if ((rc = bwd_block_apply(c, i, (double)c->B, STREAM))) return rc;
+    }
+    return bwd_end(c, STREAM);
+}
+
+extern "C" int dun_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum,
+                            float weight_decay, dun_stream_t stream) {
+    DUN_REQUIRE(p && g && buf, "dun_sgd_step: null pointer");
+    DUN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(buf), "dun_sgd_step: buffers must be 16-byte aligned");
+    if (n == 0) return DUN_OK;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, p, g, buf, n, lr, momentum, weight_decay);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}

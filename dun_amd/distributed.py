@@ -1,0 +1,64 @@
+"""Batch-sharded data parallelism for the DUN path: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The reference has no distributed code; this is the sharding the north-star asks for.  Samples
+are independent through Linear / ReLU / head / likelihood, so rank r just takes its rows.  What couples samples
+is exchanged explicitly, and nothing else is:
+  * BatchNorm batch statistics: fp64 [2,W] sums per block, forward and backward (``sync_bn=True`` reproduces the
+    single-device numerics of the full batch; ``False`` gives per-replica statistics like DataParallel would);
+  * the per-depth likelihood sums: one fp64 [D] all-reduce per step (the VI backward does not wait for it);
+  * parameter gradients: SUM all-reduce (the loss already carries 1/global_batch), issued per block while the
+    backward of the shallower blocks is still running, so the 16 MB-per-block messages overlap with the GEMMs.
+All ranks must hold the same number of rows (global batch = local batch * world size).
+"""
+import torch
+import torch.distributed as dist
+
+
+class Shard(object):
+    def __init__(self, group=None, sync_bn=True, overlap=True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.sync_bn = sync_bn
+        self.overlap = overlap
+        self._pending = []
+
+    def global_batch(self, local_batch):
+        return local_batch * self.world
+
+    def all_reduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def reduce_gradient_async(self, t, exclude=None):
+        """SUM all-reduce of a gradient slice; `exclude` is a sub-range of `t`'s storage that was already sent."""
+        if self.world == 1:
+            return
+        pieces = [t]
+        if exclude is not None:
+            flat = t.reshape(-1)
+            lo = exclude.storage_offset() - t.storage_offset()
+            hi = lo + exclude.numel()
+            pieces = [p for p in (flat[:lo], flat[hi:]) if p.numel()]
+        for p in pieces:
+            if self.overlap:
+                self._pending.append(dist.all_reduce(p, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                dist.all_reduce(p, op=dist.ReduceOp.SUM, group=self.group)
+
+    def wait_gradients(self):
+        for h in self._pending:
+            h.wait()
+        self._pending = []
+
+
+def shard(net, group=None, sync_bn=True, overlap=True):
+    """Make a DUN / DUN_VI wrapper train on this rank's shard of every global batch."""
+    spec = Shard(group, sync_bn=sync_bn, overlap=overlap)
+    net.model._dist = spec
+    net.prob_model._dist = spec
+    net._dist = spec
+    return spec

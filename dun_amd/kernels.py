@@ -1,0 +1,252 @@
+"""Tensor-level entry to the HIP kernels (through the C ABI in include/dun_hip.h).
+
+Everything the rest of the package computes on the hot path goes through the object returned by
+``backend()``.  The product backend is ``HipBackend``; it has no CPU path and raises on CPU tensors.
+``set_backend`` exists so that the multi-process CPU tests can drive the host-side sharding logic with a
+stand-in (tests/cpu_backend.py); nothing in the package itself ever installs another backend.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class FcBuffers(object):
+    """Device buffers of one residual-MLP trunk at a fixed (batch, depth, mode); owns the C context struct."""
+
+    def __init__(self, model, B, depth, train):
+        dev = model.flat_params.device
+        W, O, din, Lyr = model.width, model.output_dim, model.input_dim, model.n_layers
+        self.B, self.depth, self.train = B, depth, train
+        f = dict(device=dev, dtype=torch.float32)
+        self.H = torch.empty(depth + 1, B, W, **f)
+        self.Z = torch.empty((depth if train else min(depth, 1)), B, W, **f)
+        self.act = None  # a fresh [depth+1,B,O] tensor per forward (new_act): callers may keep what they get
+        self._act_shape = (depth + 1, B, O)
+        self.bn_mean = torch.empty(max(Lyr, 1), W, **f)
+        self.bn_rstd = torch.empty(max(Lyr, 1), W, **f)
+        self.bn_sums = torch.zeros(2, W, device=dev, dtype=torch.float64)
+        n_ws = L.lib().dun_fc_workspace_floats(B, din, W, O, Lyr)
+        self.ws = torch.empty(n_ws, **f)
+        self.G = None
+        self.dU = None
+        self.x = None
+        self.dact = None
+        c = L.FcCtx()
+        c.B, c.din, c.W, c.O, c.L = B, din, W, O, Lyr
+        c.residual, c.train, c.depth = int(model.residual), int(train), depth
+        c.bn_eps, c.bn_momentum = model.bn_eps, model.bn_momentum
+        for k in ("w_in", "b_in", "w_out", "b_out", "w", "b", "gamma", "beta"):
+            setattr(c.p, k, L.f32(model.stacked[k]))
+            setattr(c.g, k, L.f32(model.stacked_grad[k]))
+        c.running_mean, c.running_var = L.f32(model.running_mean), L.f32(model.running_var)
+        c.H, c.Z = L.f32(self.H), (L.f32(self.Z) if self.Z.numel() else None)
+        c.bn_mean, c.bn_rstd, c.bn_sums = L.f32(self.bn_mean), L.f32(self.bn_rstd), L.ptr(self.bn_sums)
+        c.ws, c.ws_floats = L.f32(self.ws), n_ws
+        self.c = c
+
+    def new_act(self):
+        self.act = torch.empty(self._act_shape, device=self.H.device, dtype=torch.float32)
+        self.c.act = L.f32(self.act)
+
+    def set_input(self, x):
+        self.x = x
+        self.c.x = L.f32(x)
+
+    def ensure_backward(self):
+        if self.G is None:
+            dev = self.H.device
+            self.G = torch.empty(self.B, self.H.shape[2], device=dev, dtype=torch.float32)
+            self.dU = torch.empty_like(self.G)
+            self.c.G, self.c.dU = L.f32(self.G), L.f32(self.dU)
+
+    def set_dact(self, dact):
+        self.dact = dact
+        self.c.dact = L.f32(dact)
+
+
+class HipBackend(object):
+    name = "hip"
+
+    # ---- probability module -------------------------------------------------------------------------
+    def ll_pass(self, act, y, regression, log_std, w, w_is_logits, inv_batch, want_dact=True, want_ll=False):
+        """One streaming pass: per-depth sums (double [D]) [+ dact] [+ ll[D,B]]."""
+        lib = L.lib()
+        D, B = act.shape[0], act.shape[1]
+        dev = act.device
+        dact = torch.empty_like(act) if want_dact else None
+        ll = torch.empty(D, B, device=dev, dtype=torch.float32) if want_ll else None
+        s = L.stream_ptr(dev)
+        if regression:
+            if act.dim() == 3 and act.shape[2] != 1:
+                # same failure the reference hits at src/probability.py:171 (.view(depth, batch_size))
+                raise RuntimeError("shape '[%d, %d]' is invalid for input of size %d" % (D, B, act.numel()))
+            nparts = lib.dun_ll_num_partials(B, 1)
+            partials = torch.empty(D, nparts, device=dev, dtype=torch.float64)
+            L.check(lib.dun_ll_gauss(L.f32(act), L.f32(y), L.f32(log_std), None if w is None else L.f32(w),
+                                     int(w_is_logits), D, B, float(inv_batch), None if dact is None else L.f32(dact),
+                                     None if ll is None else L.f32(ll), L.ptr(partials), s), "dun_ll_gauss")
+        else:
+            Cn = act.shape[2]
+            if y.dtype != torch.int64:
+                raise RuntimeError("classification targets must be int64")
+            nparts = lib.dun_ll_num_partials(B, max(Cn, 2))
+            partials = torch.empty(D, nparts, device=dev, dtype=torch.float64)
+            L.check(lib.dun_ll_softmax(L.f32(act), L.ptr(y), None if w is None else L.f32(w), int(w_is_logits), D, B,
+                                       Cn, float(inv_batch), None if dact is None else L.f32(dact),
+                                       None if ll is None else L.f32(ll), L.ptr(partials), s), "dun_ll_softmax")
+        sums = torch.empty(D, device=dev, dtype=torch.float64)
+        L.check(lib.dun_ll_reduce(L.ptr(partials), D, nparts, L.ptr(sums), s), "dun_ll_reduce")
+        return sums, dact, ll
+
+    def depth_finalize(self, sums, gaussian, q_logits, logprior, prior_ll, log_std, N_train, batch, beta, eps,
+                       objective):
+        D = sums.shape[0]
+        res = torch.empty(L.res_floats(D), device=sums.device, dtype=torch.float32)
+        L.check(L.lib().dun_depth_finalize(
+            L.ptr(sums), int(gaussian), None if q_logits is None else L.f32(q_logits), L.f32(logprior),
+            None if prior_ll is None else L.f32(prior_ll), None if log_std is None else L.f32(log_std), D,
+            float(N_train), float(batch), float(beta), float(eps), int(objective), L.f32(res),
+            L.stream_ptr(sums.device)), "dun_depth_finalize")
+        return res
+
+    def predict(self, act, q, regression, get_std=False, y=None, log_std=None):
+        """Depth-marginal prediction; with y also the metric sums (double [2])."""
+        lib = L.lib()
+        dev = act.device
+        D = act.shape[0]
+        s = L.stream_ptr(dev)
+        q = q.detach().to(torch.float32).contiguous()
+        metrics = None
+        if regression:
+            n = act[0].numel()
+            mean = torch.empty(act.shape[1:], device=dev, dtype=torch.float32)
+            std = torch.empty_like(mean) if (get_std or y is not None) else None
+            partials = None
+            if y is not None:
+                nparts = lib.dun_predict_num_partials(n, 1)
+                partials = torch.empty(2, nparts, device=dev, dtype=torch.float64)
+                metrics = torch.empty(2, device=dev, dtype=torch.float64)
+            L.check(lib.dun_predict_gauss(L.f32(act), L.f32(q), D, n, L.f32(mean), None if std is None else L.f32(std),
+                                          None if y is None else L.f32(y), None if y is None else L.f32(log_std),
+                                          None if partials is None else L.ptr(partials),
+                                          None if metrics is None else L.ptr(metrics), s), "dun_predict_gauss")
+            return mean, std, metrics
+        B, Cn = act.shape[1], act.shape[2]
+        probs = torch.empty(B, Cn, device=dev, dtype=torch.float32)
+        partials = None
+        if y is not None:
+            nparts = lib.dun_predict_num_partials(B, max(Cn, 2))
+            partials = torch.empty(2, nparts, device=dev, dtype=torch.float64)
+            metrics = torch.empty(2, device=dev, dtype=torch.float64)
+        L.check(lib.dun_predict_softmax(L.f32(act), L.f32(q), D, B, Cn, L.f32(probs), None if y is None else L.ptr(y),
+                                        None if partials is None else L.ptr(partials),
+                                        None if metrics is None else L.ptr(metrics), s), "dun_predict_softmax")
+        return probs, None, metrics
+
+    # ---- trunk ----------------------------------------------------------------------------------------
+    def fc_buffers(self, model, B, depth, train):
+        return FcBuffers(model, B, depth, train)
+
+    def _fc(self, name, buf, *args):
+        fn = getattr(L.lib(), name)
+        L.check(fn(C.byref(buf.c), *args, L.stream_ptr(buf.H.device)), name)
+
+    def fc_forward(self, buf):
+        self._fc("dun_fc_forward", buf)
+
+    def fc_backward(self, buf):
+        self._fc("dun_fc_backward", buf)
+
+    def fc_input_layer(self, buf):
+        self._fc("dun_fc_input_layer", buf)
+
+    def fc_block_linear(self, buf, i):
+        self._fc("dun_fc_block_linear", buf, i)
+
+    def fc_block_norm(self, buf, i, global_batch):
+        self._fc("dun_fc_block_norm", buf, i, float(global_batch))
+
+    def fc_head(self, buf):
+        self._fc("dun_fc_head", buf)
+
+    def fc_bwd_begin(self, buf):
+        self._fc("dun_fc_bwd_begin", buf)
+
+    def fc_bwd_block_reduce(self, buf, i):
+        self._fc("dun_fc_bwd_block_reduce", buf, i)
+
+    def fc_bwd_block_apply(self, buf, i, global_batch):
+        self._fc("dun_fc_bwd_block_apply", buf, i, float(global_batch))
+
+    def fc_bwd_end(self, buf):
+        self._fc("dun_fc_bwd_end", buf)
+
+    # ---- shared head over all exits -------------------------------------------------------------------
+    def head_forward(self, H, w, b):
+        rows, K = H.shape[0], H.shape[1]
+        O = w.shape[0]
+        act = torch.empty(rows, O, device=H.device, dtype=torch.float32)
+        L.check(L.lib().dun_head_forward(L.f32(H), L.f32(w), L.f32(b), rows, K, O, L.f32(act), L.stream_ptr(H.device)),
+                "dun_head_forward")
+        return act
+
+    def head_backward(self, H, w, dact, need_dH=True):
+        lib = L.lib()
+        rows, K = H.shape[0], H.shape[1]
+        O = w.shape[0]
+        dw = torch.empty_like(w)
+        db = torch.empty(O, device=H.device, dtype=torch.float32)
+        dH = torch.empty_like(H) if need_dH else None
+        n_ws = lib.dun_head_backward_workspace_floats(rows, K, O)
+        ws = torch.empty(n_ws, device=H.device, dtype=torch.float32)
+        L.check(lib.dun_head_backward(L.f32(H), L.f32(w), L.f32(dact), rows, K, O, L.f32(dw), L.f32(db),
+                                      None if dH is None else L.f32(dH), L.f32(ws), n_ws, L.stream_ptr(H.device)),
+                "dun_head_backward")
+        return dw, db, dH
+
+    # ---- optimiser ------------------------------------------------------------------------------------
+    def sgd_step(self, p, g, buf, lr, momentum, weight_decay):
+        L.check(L.lib().dun_sgd_step(L.f32(p), L.f32(g), L.f32(buf), p.numel(), float(lr), float(momentum),
+                                     float(weight_decay), L.stream_ptr(p.device)), "dun_sgd_step")
+
+    # ---- raw GEMM (tests / benchmarks) ----------------------------------------------------------------
+    def gemm(self, A, B, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, relu=False, R=None, U=None, V=None,
+             colstats=False, out=None):
+        dev = A.device
+        Cm = out if out is not None else torch.empty(M, N, device=dev, dtype=torch.float32)
+        d = L.GemmDesc()
+        d.A, d.B, d.C = L.f32(A), L.f32(B), L.f32(Cm)
+        d.M, d.N, d.K = M, N, K
+        d.lda, d.ldb, d.ldc = A.shape[1], B.shape[1], N
+        d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
+        d.bias = None if bias is None else L.f32(bias)
+        d.relu = int(relu)
+        if R is not None:
+            d.R, d.ldr = L.f32(R), R.shape[1]
+        if U is not None:
+            d.U, d.V, d.O, d.ldv = L.f32(U), L.f32(V), U.shape[1], V.shape[1]
+        stats = None
+        if colstats:
+            stats = torch.empty(2, (M + 127) // 128, N, device=dev, dtype=torch.float32)
+            d.colstats = L.f32(stats)
+        L.check(L.lib().dun_gemm_f32(C.byref(d), L.stream_ptr(dev)), "dun_gemm_f32")
+        return (Cm, stats) if colstats else Cm
+
+
+_backend = None
+
+
+def backend():
+    global _backend
+    if _backend is None:
+        L.lib()  # fail loudly, now, if the HIP library was never built
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(b):
+    """Test seam only (see module docstring)."""
+    global _backend
+    _backend = b

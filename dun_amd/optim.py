@@ -1,0 +1,59 @@
+"""Fused SGD(momentum, weight_decay): one kernel over each flat parameter buffer.
+
+Numerics are torch.optim.SGD's (dampening 0, no nesterov) as the reference configures it at
+src/DUN/training_wrappers.py:48-52 -- including weight decay on q_logits and log_std, which share the single
+parameter group.  Parameters that live in a model's flat buffer (dun_amd.stochastic_fc_models) are stepped with
+ONE launch for the whole buffer; any other parameter (q_logits, log_std, the conv trunk of image DUNs) gets the
+same kernel per tensor.  A parameter whose ``.grad`` is None is skipped, like torch does (q warm-up).
+"""
+import torch
+
+from . import kernels
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-2, momentum=0.0, weight_decay=0.0):
+        defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay)
+        super(FusedSGD, self).__init__(params, defaults)
+
+    def zero_grad(self, set_to_none=True):
+        # flat-buffer gradients are overwritten by every backward and must stay attached to their buffer
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "_dun_flat_owner", None) is None:
+                    if set_to_none:
+                        p.grad = None
+                    elif p.grad is not None:
+                        p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        be = kernels.backend()
+        for group in self.param_groups:
+            lr, mom, wd = group["lr"], group["momentum"], group["weight_decay"]
+            owners = []
+            for p in group["params"]:
+                owner = getattr(p, "_dun_flat_owner", None)
+                if owner is not None:
+                    if not any(o is owner for o in owners):
+                        owners.append(owner)
+                    continue
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if "momentum_buffer" not in st:
+                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                be.sgd_step(p.data, g, st["momentum_buffer"], lr, mom, wd)
+            for owner in owners:
+                st = self.state[owner._param_list[0]]
+                buf = st.get("flat_momentum_buffer")
+                if buf is None or buf.shape != owner.flat_params.shape or buf.device != owner.flat_params.device:
+                    buf = torch.zeros_like(owner.flat_params)
+                    st["flat_momentum_buffer"] = buf
+                be.sgd_step(owner.flat_params, owner.flat_grads, buf, lr, mom, wd)
+        return loss

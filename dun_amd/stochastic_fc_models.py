@@ -1,0 +1,245 @@
+"""Residual-MLP / plain-MLP DUN trunks with the reference's constructor and attribute surface.
+
+Reference: src/DUN/stochastic_fc_models.py:7-80.  ``forward(x, depth=None)`` returns ``act_vec [D,B,O]``
+(the north-star's "forward_get_acts"; an alias of that name is provided).  All arithmetic of ``forward``
+and its backward runs in the HIP trunk kernels (dun_amd/csrc/trunk.hip, gemm.hip, head.hip): the module's
+parameters are views into one flat fp32 buffer that the kernels, the fused SGD step and the gradient
+all-reduce address directly; gradients land in a second flat buffer whose views are the parameters' ``.grad``.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels
+from .layers import bern_MLPBlock, bern_MLPBlock_nores
+
+_SEG_ALIGN = 64  # floats: every segment of the flat buffers starts on a 256-byte boundary
+_KINDS = ("w_in", "b_in", "w_out", "b_out", "w", "b", "gamma", "beta")
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+class _FcForward(torch.autograd.Function):
+    """Autograd node of the whole trunk.  Parameter gradients are written by the kernels straight into the
+    flat gradient buffer (``p.grad`` views), not returned to autograd, and overwrite what was there."""
+
+    @staticmethod
+    def forward(ctx, model, x, depth, *params):
+        buf = model._run_forward(x, depth, True)
+        ctx.model, ctx.buf = model, buf
+        return buf.act
+
+    @staticmethod
+    def backward(ctx, dact):
+        ctx.model._run_backward(ctx.buf, dact)
+        return (None, None, None) + (None,) * len(ctx.model._param_list)
+
+
+class arq_uncert_fc_resnet(nn.Module):
+    residual = True
+    _block_cls = bern_MLPBlock
+
+    def __init__(self, input_dim, output_dim, width, n_layers, w_prior=None, BMA_prior=False):
+        super(arq_uncert_fc_resnet, self).__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        # same construction order as the reference, so an identical torch seed gives identical initial weights
+        self.input_layer = nn.Linear(self.input_dim, width)
+        self.output_layer = nn.Linear(width, self.output_dim)
+        self.n_layers = n_layers
+        self.width = width
+        self.w_prior = w_prior
+        self.BMA_prior = BMA_prior
+        if not isinstance(self.w_prior, list) and self.w_prior is not None:
+            self.w_prior = [self.w_prior for _ in range(self.n_layers + 1)]
+        self.stochstic_layers = nn.ModuleList()
+        for _ in range(self.n_layers):
+            self.stochstic_layers.append(self._block_cls(width))
+        self.bn_eps, self.bn_momentum = 1e-5, 0.1
+        self._dist = None      # set by dun_amd.distributed.shard(): batch-sharded data parallelism
+        self._fc_cache = {}
+        self._flatten()
+
+    # ---- flat parameter / gradient storage ---------------------------------------------------------
+    def _segments(self):
+        W, L, O, din = self.width, self.n_layers, self.output_dim, self.input_dim
+        sizes = dict(w_in=W * din, b_in=W, w_out=O * W, b_out=O, w=L * W * W, b=L * W, gamma=L * W, beta=L * W)
+        shapes = dict(w_in=(W, din), b_in=(W,), w_out=(O, W), b_out=(O,), w=(L, W, W), b=(L, W), gamma=(L, W),
+                      beta=(L, W))
+        offs, o = {}, 0
+        for k in _KINDS:
+            offs[k] = o
+            o += _round_up(sizes[k], _SEG_ALIGN)
+        return sizes, shapes, offs, max(o, _SEG_ALIGN)
+
+    def _module_params(self):
+        """(kind, layer index or None, Parameter) in flat-buffer order."""
+        out = [("w_in", None, self.input_layer.weight), ("b_in", None, self.input_layer.bias),
+               ("w_out", None, self.output_layer.weight), ("b_out", None, self.output_layer.bias)]
+        for kind, sub, attr in (("w", 0, "weight"), ("b", 0, "bias"), ("gamma", 2, "weight"), ("beta", 2, "bias")):
+            for i, blk in enumerate(self.stochstic_layers):
+                out.append((kind, i, getattr(blk.block[sub], attr)))
+        return out
+
+    def _flatten(self):
+        sizes, shapes, offs, total = self._segments()
+        dev = self.input_layer.weight.device
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        gflat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.stacked, self.stacked_grad = {}, {}
+        for k in _KINDS:
+            self.stacked[k] = flat[offs[k]:offs[k] + sizes[k]].view(shapes[k])
+            self.stacked_grad[k] = gflat[offs[k]:offs[k] + sizes[k]].view(shapes[k])
+        self._param_list, self._grad_views = [], []
+        with torch.no_grad():
+            for kind, i, p in self._module_params():
+                dst = self.stacked[kind] if i is None else self.stacked[kind][i]
+                gdst = self.stacked_grad[kind] if i is None else self.stacked_grad[kind][i]
+                dst.copy_(p.data.to(torch.float32))
+                p.data = dst
+                p.grad = gdst
+                p._dun_flat_owner = self
+                self._param_list.append(p)
+                self._grad_views.append(gdst)
+            L, W = self.n_layers, self.width
+            rm = torch.zeros(L, W, device=dev)
+            rv = torch.ones(L, W, device=dev)
+            nbt = torch.zeros(L, device=dev, dtype=torch.int64)
+            for i, blk in enumerate(self.stochstic_layers):
+                bn = blk.block[2]
+                rm[i].copy_(bn.running_mean)
+                rv[i].copy_(bn.running_var)
+                nbt[i] = bn.num_batches_tracked
+                bn.running_mean = rm[i]
+                bn.running_var = rv[i]
+                bn.num_batches_tracked = nbt[i]
+        self.flat_params, self.flat_grads = flat, gflat
+        self.running_mean, self.running_var, self.num_batches_tracked = rm, rv, nbt
+        self._fc_cache = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        super(arq_uncert_fc_resnet, self)._apply(fn, *args, **kwargs)
+        if hasattr(self, "flat_params"):
+            self._flatten()  # .cuda()/.to() re-created the tensors: rebuild the flat views on the new device
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super(arq_uncert_fc_resnet, self).load_state_dict(state_dict, strict=strict, **kw)
+        self._flatten()
+        return out
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_fc_cache"] = {}
+        st["_dist"] = None
+        for k in ("stacked", "stacked_grad", "_param_list", "_grad_views", "flat_params", "flat_grads",
+                  "running_mean", "running_var", "num_batches_tracked"):
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        super(arq_uncert_fc_resnet, self).__setstate__(st)
+        self._flatten()
+
+    # ---- weight priors: O(#params) torch reductions, not part of the per-sample path ----
+    def apply_prior(self, module, prior_f):
+        if isinstance(module, (nn.Linear, nn.Conv2d, nn.Conv1d)):
+            self.loglike = self.loglike + prior_f(module.weight)
+            self.loglike = self.loglike + prior_f(module.bias)
+
+    def get_w_prior_loglike(self, k=None):
+        if k is None:
+            k = self.n_layers
+        if self.w_prior is None:
+            return self.input_layer.bias.data.new_zeros(k + 1)
+        self.loglike = 0
+        self.input_layer.apply(lambda m: self.apply_prior(m, self.w_prior[0]))
+        self.output_layer.apply(lambda m: self.apply_prior(m, self.w_prior[0]))
+        self.loglikes = [self.loglike]
+        for idx, layer in enumerate(self.stochstic_layers[:k]):
+            self.loglike = 0
+            layer.apply(lambda m: self.apply_prior(m, self.w_prior[idx + 1]))
+            self.loglikes.append(self.loglike)
+        loglike_vec = torch.stack(self.loglikes, dim=0)
+        if self.BMA_prior:
+            loglike_vec = loglike_vec.unsqueeze(0).repeat(k + 1, 1).tril(diagonal=0).sum(dim=1)
+        return loglike_vec.sum(dim=0)
+
+    # ---- cold path: explicit 0/1 mask per block, torch ops (plots only) -------------------
+    def vec_forward(self, x, vec):
+        assert vec.shape[0] == self.n_layers
+        x = self.input_layer(x)
+        for i in range(self.n_layers):
+            x = self.stochstic_layers[i](x, vec[i])
+        return self.output_layer(x)
+
+    # ---- hot path ---------------------------------------------------------------------------------------
+    def _get_buffers(self, B, depth, train):
+        key = (B, depth, bool(train))
+        buf = self._fc_cache.get(key)
+        if buf is None:
+            if len(self._fc_cache) >= 4:  # keep the cache bounded: training + a few inference shapes
+                for k in [k for k in self._fc_cache if not k[2]][:1] or list(self._fc_cache)[:1]:
+                    del self._fc_cache[k]
+            buf = kernels.backend().fc_buffers(self, B, depth, train)
+            self._fc_cache[key] = buf
+        return buf
+
+    def _run_forward(self, x, depth, train):
+        if x.dim() != 2 or x.shape[1] != self.input_dim:
+            raise RuntimeError("expected x of shape [B, %d], got %s" % (self.input_dim, tuple(x.shape)))
+        be = kernels.backend()
+        x = x.detach().to(torch.float32).contiguous()
+        buf = self._get_buffers(x.shape[0], depth, train)
+        buf.new_act()
+        buf.set_input(x)
+        dist = self._dist
+        if dist is None or not (train and dist.sync_bn) or depth == 0:
+            be.fc_forward(buf)
+        else:
+            gb = dist.global_batch(x.shape[0])
+            be.fc_input_layer(buf)
+            for i in range(depth):
+                be.fc_block_linear(buf, i)
+                dist.all_reduce(buf.bn_sums)
+                be.fc_block_norm(buf, i, gb)
+            be.fc_head(buf)
+        if train and depth > 0:
+            self.num_batches_tracked[:depth] += 1
+        return buf
+
+    def _run_backward(self, buf, dact):
+        be = kernels.backend()
+        buf.ensure_backward()
+        buf.set_dact(dact.detach().to(torch.float32).contiguous())
+        dist = self._dist
+        if dist is None:
+            be.fc_backward(buf)
+        else:
+            gb = dist.global_batch(buf.B)
+            be.fc_bwd_begin(buf)
+            for i in range(self.n_layers - 1, -1, -1):
+                be.fc_bwd_block_reduce(buf, i)
+                if dist.sync_bn:
+                    dist.all_reduce(buf.bn_sums)
+                be.fc_bwd_block_apply(buf, i, gb if dist.sync_bn else buf.B)
+                dist.reduce_gradient_async(self.stacked_grad["w"][i])
+            be.fc_bwd_end(buf)
+            dist.reduce_gradient_async(self.flat_grads, exclude=self.stacked_grad["w"])
+        for p, g in zip(self._param_list, self._grad_views):
+            if p.grad is not g:
+                p.grad = g
+
+    def forward(self, x, depth=None):
+        depth = self.n_layers if depth is None else depth
+        if self.training and torch.is_grad_enabled():
+            return _FcForward.apply(self, x, depth, *self._param_list)
+        return self._run_forward(x, depth, self.training).act
+
+    forward_get_acts = forward
+
+
+class arq_uncert_fc_MLP(arq_uncert_fc_resnet):
+    residual = False
+    _block_cls = bern_MLPBlock_nores

@@ -1,0 +1,249 @@
+"""DUN / DUN_VI training wrappers with the reference's API (src/DUN/training_wrappers.py:11-271).
+
+Same constructor arguments, methods, return types and tensor shapes.  What differs is underneath:
+  * ``fit`` runs trunk forward -> ONE fused likelihood/ELBO pass that also yields d loss / d act_vec -> trunk
+    backward -> ONE fused SGD kernel over the flat parameter buffer -> ONE fused metrics kernel, and brings the
+    three returned scalars to the host with a single copy (the reference syncs three times);
+  * the train metrics are computed, like in the reference, from the pre-step activations with the POST-step
+    q(d) for VI (training_wrappers.py:229-242) and with the pre-step exact posterior for MLL (:72-79);
+  * with ``dun_amd.distributed.shard(net)`` every call works on this rank's rows of a global batch.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import kernels
+from .optim import FusedSGD
+from .probability import depth_categorical, homo_Gauss_mloglike
+from .utils import BaseNet, cprint, to_variable
+
+
+class DUN(BaseNet):
+    def __init__(self, model, prob_model, N_train, lr=1e-2, momentum=0.5, weight_decay=0,
+                 cuda=True, schedule=None, regression=False, pred_sig=None):
+        super(DUN, self).__init__()
+        cprint('y', 'DUN learnt with marginal likelihood categorical output')
+        self.lr = lr
+        self.momentum = momentum
+        self.weight_decay = weight_decay
+        self.model = model
+        self.prob_model = prob_model
+        self.cuda = cuda
+        self.regression = regression
+        self.pred_sig = pred_sig
+        if self.regression:
+            self.f_neg_loglike = homo_Gauss_mloglike(self.model.output_dim, self.pred_sig)
+            self.f_neg_loglike_test = self.f_neg_loglike
+        else:
+            self.f_neg_loglike = nn.CrossEntropyLoss(reduction='none')  # takes logits
+            self.f_neg_loglike_test = nn.NLLLoss(reduction='none')  # takes log probs
+        self.N_train = N_train
+        self._dist = None
+        self.create_net()
+        self.create_opt()
+        self.schedule = schedule
+        if self.schedule is not None and len(self.schedule) > 0:
+            self.make_scheduler(gamma=0.1, milestones=self.schedule)
+        self.epoch = 0
+
+    def create_net(self):
+        if self.cuda:
+            self.model.cuda()
+            self.f_neg_loglike.cuda()
+            torch.backends.cudnn.benchmark = True  # MIOpen find mode for the conv trunks of image DUNs
+        print('    Total params: %.2fM' % (self.get_nb_parameters() / 1000000.0))
+
+    def create_opt(self):
+        param_list = list(self.model.parameters()) + list(self.prob_model.parameters())
+        if self.regression and self.pred_sig is None:
+            param_list += list(self.f_neg_loglike.parameters())
+        self.optimizer = FusedSGD(param_list, lr=self.lr, momentum=self.momentum, weight_decay=self.weight_decay)
+
+    # ---- shared pieces of fit -----------------------------------------------------------------------
+    def _prepare(self, x, y):
+        x, y = to_variable(var=(x, y), cuda=self.cuda)
+        if not self.regression:
+            y = y.long()
+        return x, y
+
+    def _backward(self, act_vec, prior_loglikes, out):
+        """Backward of loss = -objective / N_train from the fused pass's d loss / d act_vec."""
+        roots, grads = [act_vec], [out.dact.view_as(act_vec)]
+        if isinstance(prior_loglikes, torch.Tensor) and prior_loglikes.requires_grad:
+            w = out.weights.detach()
+            prior_term = (w * prior_loglikes).sum() if prior_loglikes.dim() == 1 and prior_loglikes.shape[0] == out.D \
+                else w.sum() * prior_loglikes.sum()
+            roots.append(-prior_term / self.N_train)
+            grads.append(None)
+        torch.autograd.backward(roots, grads)
+        q_logits = getattr(self.prob_model, "q_logits", None)
+        if q_logits is not None and q_logits.requires_grad:
+            q_logits.grad = out.dq_logits.clone()
+        if self.regression and self.f_neg_loglike.log_std.requires_grad:
+            self.f_neg_loglike.log_std.grad = out.dlog_std.clone().reshape(self.f_neg_loglike.log_std.shape)
+        if self._dist is not None:
+            self._reduce_loose_gradients()
+            self._dist.wait_gradients()
+
+    def _reduce_loose_gradients(self):
+        """Sharded job: sum the gradients that do not live in a flat buffer (conv trunks of image DUNs)."""
+        loose = [p.grad for p in self.model.parameters()
+                 if getattr(p, "_dun_flat_owner", None) is None and p.grad is not None]
+        if loose and self._dist.world > 1:
+            flat = torch._utils._flatten_dense_tensors(loose)
+            self._dist.all_reduce(flat)
+            for g, r in zip(loose, torch._utils._unflatten_dense_tensors(flat, loose)):
+                g.copy_(r)
+
+    def _metrics(self, act_vec, y, objective):
+        """(objective, mean predictive NLL, err) as Python floats with ONE device->host copy."""
+        be = kernels.backend()
+        act = act_vec.detach()
+        post = self.prob_model.current_posterior
+        if self.regression:
+            _, _, m = be.predict(act, post, True, get_std=True, y=y.to(torch.float32).contiguous(),
+                                 log_std=self.f_neg_loglike.log_std.detach())
+            n = act[0].numel()
+        else:
+            _, _, m = be.predict(act, post, False, y=y.contiguous())
+            n = act.shape[1]
+        if self._dist is not None:
+            self._dist.all_reduce(m)
+            n = self._dist.global_batch(n)
+        if objective is None:
+            nll_sum, err_sum = m.tolist()
+            obj = None
+        else:
+            obj, nll_sum, err_sum = torch.cat([objective.detach().reshape(1).double(), m]).tolist()
+        nll = nll_sum / n
+        err = (err_sum / n) ** 0.5 if self.regression else err_sum / n
+        return obj, nll, err
+
+    def fit(self, x, y):
+        """Optimise the stochastically estimated marginal joint of parameters and weights"""
+        self.model.train()
+        x, y = self._prepare(x, y)
+        self.optimizer.zero_grad()
+
+        act_vec = self.model.forward(x)
+        prior_loglikes = self.model.get_w_prior_loglike(k=None)
+        out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train)
+        self._backward(act_vec, prior_loglikes, out)
+        self.optimizer.step()
+
+        # this posterior is one iteration behind the parameters: estimated with the acts from before the step
+        self.prob_model.current_posterior = out.posterior.clone()
+        return self._metrics(act_vec, y, out.log_marg)
+
+    def eval(self, x, y):
+        self.model.eval()
+        with torch.no_grad():
+            x, y = self._prepare(x, y)
+            act_vec = self.model.forward(x)
+            _, nll, err = self._metrics(act_vec, y, None)
+            return nll, err
+
+    def layer_predict(self, x):
+        self.model.eval()
+        x, = to_variable(var=(x, ), cuda=self.cuda)
+        with torch.no_grad():
+            out = self.model.forward(x).data
+        if not self.regression:
+            out = F.softmax(out, dim=2)
+        return out
+
+    def vec_predict(self, x, bin_mat):
+        """Get predictions for specific binary vector configurations (cold path: torch ops)"""
+        self.model.eval()
+        x, = to_variable(var=(x, ), cuda=self.cuda)
+        out = x.data.new(bin_mat.shape[0], x.shape[0], self.model.output_dim)
+        with torch.no_grad():
+            for s in range(bin_mat.shape[0]):
+                out[s] = self.model.vec_forward(x, bin_mat[s, :]).data
+        # (the reference only defines `probs` for classification and raises for regression)
+        if not self.regression:
+            probs = F.softmax(out, dim=2)
+        return probs.data
+
+    def predict(self, x, depth=None, get_std=False, return_model_std=False):
+        self.model.eval()
+        with torch.no_grad():
+            x, = to_variable(var=(x,), cuda=self.cuda)
+            act_vec = self.model.forward(x, depth=depth).data
+            if get_std:
+                pred_mu, model_std = depth_categorical.marginalise_d_predict(
+                    act_vec, self.prob_model.current_posterior, depth=depth, softmax=(not self.regression),
+                    get_std=get_std)
+                if return_model_std:
+                    return pred_mu.data, model_std.data
+                pred_std = (model_std ** 2 + self.f_neg_loglike.log_std.exp() ** 2).pow(0.5)
+                return pred_mu.data, pred_std.data
+            probs = depth_categorical.marginalise_d_predict(act_vec, self.prob_model.current_posterior, depth=depth,
+                                                            softmax=(not self.regression), get_std=get_std)
+            return probs.data
+
+    def fast_predict(self, x):
+        self.model.eval()
+        with torch.no_grad():
+            x, = to_variable(var=(x,), cuda=self.cuda)
+            act_vec = self.model.fast_forward_impl(x, self.prob_model.current_posterior, min_prob=1e-2).data
+            probs = depth_categorical.marginalise_d_predict(act_vec, self.prob_model.current_posterior, depth=None,
+                                                            softmax=True, get_std=False)
+            return probs.data
+
+    def _sweep(self, trainloader, train_bn, vi):
+        if train_bn:
+            self.model.train()
+        else:
+            self.model.eval()
+        with torch.no_grad():
+            prior_loglikes = self.model.get_w_prior_loglike(k=None)
+            N_train = len(trainloader.dataset)
+            assert N_train == self.N_train
+            cum = None
+            for x, y in trainloader:
+                x, y = self._prepare(x, y)
+                act_vec = self.model.forward(x)
+                if vi:
+                    out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, N_train,
+                                                          want_grad=False)
+                    term = (x.shape[0] / N_train) * out.objective.double()
+                else:
+                    out = depth_categorical.fused_objective(self.prob_model, prior_loglikes, act_vec, y,
+                                                            self.f_neg_loglike, N_train, want_grad=False)
+                    term = (x.shape[0] / N_train) * out.joint.double()
+                cum = term if cum is None else cum + term
+            return cum
+
+    def get_exact_d_posterior(self, trainloader, train_bn=False, logposterior=False):
+        """Exact posterior over depth and log marginal over weights with a full pass over the data"""
+        cum = self._sweep(trainloader, train_bn, vi=False).float()
+        log_marg = self.prob_model.get_marg_loglike(cum)
+        log_post = self.prob_model.get_depth_log_posterior(cum, log_marg)
+        exact_posterior = log_post if logposterior else log_post.exp()
+        return exact_posterior, log_marg.item()
+
+
+class DUN_VI(DUN):
+    def __init__(self, model, prob_model, N_train, lr=1e-2, momentum=0.5, weight_decay=0, cuda=True,
+                 schedule=None, regression=False, pred_sig=None):
+        super(DUN_VI, self).__init__(model, prob_model, N_train, lr, momentum, weight_decay, cuda,
+                                     schedule, regression, pred_sig)
+
+    def fit(self, x, y):
+        """Optimise the ELBO over weights and q(d)"""
+        self.set_mode_train(train=True)
+        x, y = self._prepare(x, y)
+        self.optimizer.zero_grad()
+
+        act_vec = self.model.forward(x)
+        prior_loglikes = self.model.get_w_prior_loglike(k=None)
+        out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train, Beta=1)
+        self._backward(act_vec, prior_loglikes, out)
+        self.optimizer.step()
+        self.prob_model.current_posterior = self.prob_model.get_q_probs().detach()
+        return self._metrics(act_vec, y, out.objective)
+
+    def get_exact_ELBO(self, trainloader, train_bn=False):
+        """Exact ELBO with a full pass over the data"""
+        return self._sweep(trainloader, train_bn, vi=True).item()

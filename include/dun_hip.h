@@ -1,0 +1,207 @@
+/*
+ * dun_hip.h -- C ABI of libdun_hip.so: the MI355X (gfx950) kernels behind DUN's depth-marginalised
+ * training / prediction path.
+ *
+ * The reference (cambridge-mlg/DUN) is pure Python/PyTorch and has no FFI; this header is the boundary a
+ * maintainer would bind (ctypes stub in INTEGRATION.md) to replace the ATen op sequences cited at each entry.
+ * All pointers are DEVICE pointers unless a comment says host.  All tensors are dense, row-major fp32 unless
+ * stated.  Every entry returns DUN_OK (0) or an error code; dun_last_error() gives the message.  No entry
+ * allocates or frees device memory or synchronises the device: scratch comes in through workspace arguments
+ * and kernels are enqueued on the hipStream_t passed as `stream`.
+ *
+ * Citations are file:line in the reference repository.
+ */
+#ifndef DUN_HIP_H
+#define DUN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUN_OK 0
+#define DUN_ERR_INVALID 1     /* bad shape / null pointer / misuse, nothing was launched */
+#define DUN_ERR_LAUNCH 2      /* HIP reported a launch error */
+#define DUN_ERR_UNSUPPORTED 3 /* valid request outside the implemented range (e.g. > 1024 classes) */
+
+#define DUN_OBJ_VI 0  /* ELBO with learnt categorical q(d): DUN_VI.fit, src/DUN/training_wrappers.py:220-229 */
+#define DUN_OBJ_MLL 1 /* exact marginal over depth (logsumexp): DUN.fit, src/DUN/training_wrappers.py:62-74 */
+
+typedef void* dun_stream_t; /* hipStream_t */
+
+int dun_abi_version(void);
+const char* dun_last_error(void); /* host string, valid until the next failing call on this thread */
+
+/* ------------------------------------------------------------------------------------------------------
+ * Probability module: fused per-depth likelihood pass + depth reduction + ELBO / marginal + backward.
+ * Replaces depth_categorical.get_w_joint_loglike (src/probability.py:162-174), homo_Gauss_mloglike.forward
+ * (src/probability.py:54-60), nn.CrossEntropyLoss(reduction='none') (src/DUN/training_wrappers.py:29),
+ * get_marg_loglike / get_depth_log_posterior (src/probability.py:176-186), depth_categorical_VI.get_KL /
+ * get_E_loglike / estimate_ELBO (src/probability.py:232-253) and autograd's backward through them.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Number of double partials per depth the likelihood passes write (one per workgroup along the batch). */
+int dun_ll_num_partials(int B, int C);
+
+/* Gaussian pass, one output dimension (the reference's view(depth,batch) only works for O == 1).
+ *   act [D,B], y [B], log_std [1].
+ *   partials (double [D, dun_ll_num_partials(B,1)]): per-workgroup sums of r^2 = (y-act)^2.
+ *   w: NULL (forward only) or [D] depth weights; w_is_logits != 0 -> softmax(w) is applied on device
+ *      (q = softmax(q_logits), src/probability.py:228-230).
+ *   dact [D,B] (nullable): d(-objective/N)/d act = -(w_d * inv_batch) * (y - act) / sigma^2,
+ *      sigma = max(exp(log_std), 1e-4) (src/probability.py:55); inv_batch = 1 / (global batch size).
+ *   ll [D,B] (nullable): per-activation log-likelihood, as loglike_per_act at src/probability.py:171. */
+int dun_ll_gauss(const float* act, const float* y, const float* log_std, const float* w, int w_is_logits,
+                 int D, int B, float inv_batch, float* dact, float* ll, double* partials, dun_stream_t stream);
+
+/* Softmax cross-entropy pass.  act [D,B,C], y int64 [B].  partials: per-workgroup sums of the row
+ * log-likelihood a[y] - logsumexp(a).  dact = -(w_d * inv_batch) * (onehot(y) - softmax(a)).  C <= 1024. */
+int dun_ll_softmax(const float* act, const int64_t* y, const float* w, int w_is_logits, int D, int B, int C,
+                   float inv_batch, float* dact, float* ll, double* partials, dun_stream_t stream);
+
+/* Sum the per-workgroup partials: sums[d] = sum_j partials[d, j]  (double [D]); this is what a batch-sharded
+ * job all-reduces across ranks before dun_depth_finalize. */
+int dun_ll_reduce(const double* partials, int D, int nparts, double* sums, dun_stream_t stream);
+
+/* Layout of the result block written by dun_depth_finalize (floats). */
+#define DUN_RES_OBJECTIVE 0 /* ELBO (VI) or log marginal over depth (MLL) */
+#define DUN_RES_E_LOGLIKE 1 /* sum_d q_d joint_d (VI) */
+#define DUN_RES_KL 2        /* KL(q || prior) with the eps clamp of src/probability.py:235 */
+#define DUN_RES_LOG_MARG 3  /* logsumexp_d(joint_d + logprior_d), always */
+#define DUN_RES_DLOG_STD 4  /* d(-objective/N)/d log_std (Gaussian), 0 under the 1e-4 clamp */
+#define DUN_RES_HEADER 8
+/* followed by 5 arrays of D floats: joint[D], weights[D] (q for VI, exact posterior for MLL),
+ * dq_logits[D] (VI; zeros for MLL), posterior[D] (exact, always), loglike_sum[D] (sum_b ll[d,b]) */
+#define DUN_RES_FLOATS(D) (DUN_RES_HEADER + 5 * (D))
+
+/* sums: double [D] from dun_ll_reduce (after any all-reduce): sum_b r^2 (gaussian != 0) or sum_b ll.
+ * q_logits [D] (VI) or NULL (MLL); logprior [D]; prior_ll [D] or NULL (zeros, w_prior None:
+ * src/DUN/stochastic_fc_models.py:52); log_std [1] or NULL (classification).
+ * joint_d = (N_train / batch) * sum_b ll[d,b] + prior_ll[d]  (src/probability.py:173). */
+int dun_depth_finalize(const double* sums, int gaussian, const float* q_logits, const float* logprior,
+                       const float* prior_ll, const float* log_std, int D, double N_train, double batch,
+                       double beta, double eps, int objective, float* result, dun_stream_t stream);
+
+/* Depth-marginal prediction, replaces depth_categorical.marginalise_d_predict (src/probability.py:188-208)
+ * and, when y != NULL, the train/eval metrics of src/DUN/training_wrappers.py:76-87, 101-113, 231-242.
+ * Gaussian: act [D,n] (n = B*O), q [D] probabilities -> mean [n], std [n] (nullable) = sqrt(sum q a^2 - mean^2)
+ *   (NaN for a negative variance, as model_var.pow(0.5) in the reference).
+ *   metrics (nullable, double [2]; needs y [n] and log_std [1]): sum_b NLL(mean, y, sqrt(sigma^2 + std^2)),
+ *   sum_b (mean - y)^2.  Zero it before the call; workgroups accumulate through partials + one reduce. */
+int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std, const float* y,
+                      const float* log_std, double* partials, double* metrics, dun_stream_t stream);
+/* Softmax: act [D,B,C] -> probs [B,C] = sum_d q_d softmax(act[d,b,:]).
+ *   metrics (nullable, double [2]; needs y int64 [B]): sum_b -log probs[b,y_b], count(argmax != y). */
+int dun_predict_softmax(const float* act, const float* q, int D, int B, int C, float* probs, const int64_t* y,
+                        double* partials, double* metrics, dun_stream_t stream);
+int dun_predict_num_partials(int n, int C);
+
+/* ------------------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32, LDS-staged 128x128x32 tiles) with the fused epilogues the
+ * trunk needs.  C[M,N] = epi( sum_k A(m,k) * B(k,n) ).
+ * Replaces the nn.Linear calls of src/DUN/stochastic_fc_models.py:65-69 / src/DUN/layers.py:38 (forward)
+ * and the addmm/mm nodes autograd runs for them (backward).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct dun_gemm_desc {
+    const float* A; /* a_kcontig: A[m*lda + k], else A[k*lda + m] */
+    const float* B; /* b_kcontig: B[n*ldb + k], else B[k*ldb + n] */
+    float* C;       /* C[m*ldc + n] */
+    int M, N, K;
+    int lda, ldb, ldc;
+    int a_kcontig, b_kcontig;
+    const float* bias; /* [N] added before the activation, or NULL */
+    int relu;          /* max(.,0) after bias */
+    const float* R;    /* residual R[m*ldr + n] added after the activation, or NULL (may alias C) */
+    int ldr;
+    const float* U;    /* rank-O update: C += U[m*O + o] * V[o*ldv + n]; NULL for none */
+    const float* V;
+    int O, ldv;
+    float* colstats;   /* NULL, or [2][ceil(M/128)][N]: per 128-row tile column sums of C and C^2 */
+} dun_gemm_desc;
+int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Residual-MLP trunk ("forward_get_acts"): arq_uncert_fc_resnet.forward / arq_uncert_fc_MLP
+ * (src/DUN/stochastic_fc_models.py:62-80) with bern_MLPBlock[_nores] (src/DUN/layers.py:33-53),
+ * the shared output head applied at every depth, and the hand-derived backward of all of it.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct dun_fc_tensors {
+    float* w_in;  /* [W,din] */
+    float* b_in;  /* [W] */
+    float* w_out; /* [O,W] */
+    float* b_out; /* [O] */
+    float* w;     /* [L,W,W]  (out,in) per block */
+    float* b;     /* [L,W] */
+    float* gamma; /* [L,W] BatchNorm1d weight */
+    float* beta;  /* [L,W] BatchNorm1d bias */
+} dun_fc_tensors;
+
+typedef struct dun_fc_ctx {
+    int B, din, W, O, L;
+    int residual; /* 1: h + BN(ReLU(Lin h)) (layers.py:42); 0: BN(ReLU(Lin h)) (layers.py:53) */
+    int train;    /* 1: batch statistics + running-stat update; 0: running statistics */
+    int depth;    /* blocks to run, 0..L (predict(depth=k), training_wrappers.py:142) */
+    float bn_eps, bn_momentum;
+    dun_fc_tensors p;    /* parameters */
+    float* running_mean; /* [L,W] */
+    float* running_var;  /* [L,W] */
+    const float* x;      /* [B,din] */
+    float* H;            /* [depth+1,B,W] hidden state per depth (kept for the head and for backward) */
+    float* Z;            /* train: [depth,B,W] = ReLU(Linear) per block; eval: [B,W] scratch */
+    float* bn_mean;      /* [L,W] batch mean (train) */
+    float* bn_rstd;      /* [L,W] 1/sqrt(var+eps) (train) */
+    double* bn_sums;     /* [2,W] staging for the statistics a sharded job all-reduces */
+    float* act;          /* [depth+1,B,O] */
+    float* ws;           /* scratch, >= dun_fc_workspace_floats() floats */
+    size_t ws_floats;
+    /* backward only */
+    const float* dact;   /* [depth+1,B,O] */
+    dun_fc_tensors g;    /* gradients, same shapes as p (overwritten, not accumulated) */
+    float* G;            /* [B,W] running dL/dh */
+    float* dU;           /* [B,W] dL/d(Linear output) of the current block */
+} dun_fc_ctx;
+
+size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L);
+
+int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream);  /* whole net, BatchNorm over the local batch */
+int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream); /* whole net, needs a train-mode forward */
+
+/* The same work cut at the points where a batch-sharded job exchanges BatchNorm statistics:
+ * forward:  input_layer; for i: block_linear(i) -> [all-reduce bn_sums] -> block_norm(i, global_batch); head
+ * backward: bwd_begin; for i desc: bwd_block_reduce(i) -> [all-reduce bn_sums] -> bwd_block_apply(i, global_batch); bwd_end */
+int dun_fc_input_layer(const dun_fc_ctx* c, dun_stream_t stream);
+int dun_fc_block_linear(const dun_fc_ctx* c, int i, dun_stream_t stream);
+int dun_fc_block_norm(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream);
+int dun_fc_head(const dun_fc_ctx* c, dun_stream_t stream);
+int dun_fc_bwd_begin(const dun_fc_ctx* c, dun_stream_t stream);
+int dun_fc_bwd_block_reduce(const dun_fc_ctx* c, int i, dun_stream_t stream);
+int dun_fc_bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream);
+int dun_fc_bwd_end(const dun_fc_ctx* c, dun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Shared output head as one batched contraction over all depths: act[r,o] = sum_k H[r,k] w[o,k] + b[o],
+ * r over D*B rows.  FC: output_layer at every depth (src/DUN/stochastic_fc_models.py:66,69); image DUNs:
+ * output_block on the pooled features of every exit (src/DUN/stochastic_img_resnets.py:283-285).
+ * Backward: dw[o,k] = sum_r dact[r,o] H[r,k], db[o] = sum_r dact[r,o], dH[r,k] = sum_o dact[r,o] w[o,k]
+ * (dH nullable: the FC trunk folds that term into its own backward instead).
+ * ---------------------------------------------------------------------------------------------------- */
+int dun_head_forward(const float* H, const float* w, const float* b, int rows, int K, int O, float* act,
+                     dun_stream_t stream);
+size_t dun_head_backward_workspace_floats(int rows, int K, int O);
+int dun_head_backward(const float* H, const float* w, const float* dact, int rows, int K, int O, float* dw,
+                      float* db, float* dH, float* ws, size_t ws_floats, dun_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * torch.optim.SGD(momentum, weight_decay) over one flat parameter buffer, as configured at
+ * src/DUN/training_wrappers.py:48-52: g += wd*p; buf = momentum*buf + g (buf = g on the first step, which a
+ * zero-initialised buf reproduces); p -= lr*buf.
+ * ---------------------------------------------------------------------------------------------------- */
+int dun_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
+                 dun_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUN_HIP_H */

@@ -1,0 +1,231 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the CPU oracle / golden vectors.
+
+Tolerances: integer/index results exact; fp32 results within 1e-5 relative of the reference's values (the
+north-star bar) or, where fp32 itself is ill-conditioned, within a small multiple of the reference's own
+fp32 error against an fp64 evaluation of the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dun_oracle as O
+from tests.util import Case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (run with -m 'not gpu' on CPU-only machines)")
+    from dun_amd import kernels
+    return kernels.backend()
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------
+# fp32 MFMA GEMM
+# ------------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(128, 128, 32), (256, 384, 160), (300, 100, 100), (512, 100, 13), (300, 100, 1), (1, 1, 1),
+               (129, 257, 67), (1024, 256, 256), (100, 13, 512), (64, 2048, 96), (5, 3, 1000)]
+
+
+@pytest.mark.parametrize("a_kc", [True, False])
+@pytest.mark.parametrize("b_kc", [True, False])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_layouts(be, M, N, K, a_kc, b_kc):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    A_st = A if a_kc else A.t().contiguous()        # [M,K] or [K,M]
+    B_st = B.t().contiguous() if b_kc else B         # [N,K] or [K,N]
+    C = be.gemm(dev(A_st), dev(B_st), M, N, K, a_kcontig=a_kc, b_kcontig=b_kc).cpu()
+    ref = A.double() @ B.double()
+    bound = (A.abs().double() @ B.abs().double()).max().item()
+    assert (C.double() - ref).abs().max().item() <= 4e-7 * bound + 1e-30
+
+
+@pytest.mark.parametrize("M,N,K,O", [(256, 128, 64, 1), (300, 100, 100, 1), (130, 200, 36, 3), (512, 256, 256, 10)])
+def test_gemm_epilogues(be, M, N, K, O):
+    g = torch.Generator().manual_seed(5)
+    A, Bw = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    U, V = torch.randn(M, O, generator=g), torch.randn(O, N, generator=g)
+    core = A.double() @ Bw.double().t()
+    # bias + relu + column statistics (block forward)
+    Z, st = be.gemm(dev(A), dev(Bw), M, N, K, bias=dev(bias), relu=True, colstats=True)
+    zref = torch.relu(core + bias.double())
+    assert (Z.cpu().double() - zref).abs().max().item() < 2e-5 * zref.abs().max().item()
+    s = st.cpu().double().sum(dim=1)
+    assert rel_err(s[0], zref.sum(0)) < 1e-5 and rel_err(s[1], (zref ** 2).sum(0)) < 1e-5
+    # residual (in place) + rank-O update (block backward dX)
+    Rd = dev(R.clone())
+    out = be.gemm(dev(A), dev(Bw), M, N, K, R=Rd, U=dev(U), V=dev(V), out=Rd)
+    ref = core + R.double() + U.double() @ V.double()
+    assert out.data_ptr() == Rd.data_ptr()
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------------
+# probability module
+# ------------------------------------------------------------------------------------------------------
+def _run_vi(be, act, y, regression, q_logits, log_std, N, want_ll=True):
+    D, B = act.shape[0], act.shape[1]
+    logprior = torch.full((D,), 1.0 / D).log()
+    sums, dact, ll = be.ll_pass(dev(act), dev(y), regression, None if log_std is None else dev(log_std),
+                                dev(q_logits), True, 1.0 / B, want_dact=True, want_ll=want_ll)
+    res = be.depth_finalize(sums, regression, dev(q_logits), dev(logprior), None,
+                            None if log_std is None else dev(log_std), N, B, 1.0, 1e-35, 0)
+    return res.cpu(), dact.cpu(), ll.cpu(), sums.cpu()
+
+
+@pytest.mark.parametrize("tag", ["clamp", "peaked", "one_depth", "one_row"])
+def test_elbo_gauss_edges(be, tag):
+    e = Case("edge")
+    p = "reg_%s/" % tag
+    act, y = e.t(p + "act"), e.t(p + "y")
+    ql, ls, N = e.t(p + "q_logits"), e.t(p + "log_std"), int(e[p + "N"])
+    D, B = act.shape[0], act.shape[1]
+    res, dact, ll, _ = _run_vi(be, act, y, True, ql, ls, N)
+    H = 8
+    assert rel_err(res[H:H + D], e[p + "joint"]) < 1e-5
+    assert rel_err(res[0], e[p + "ELBO"]) < 1e-5
+    assert abs(float(res[2]) - float(e[p + "KL"])) < 1e-5 * max(1.0, abs(float(e[p + "KL"])))
+    assert rel_err(res[H + D:H + 2 * D], e[p + "q"]) < 1e-5
+    assert rel_err(res[3], e[p + "log_marg"]) < 1e-5
+    assert np.allclose(res[H + 3 * D:H + 4 * D].log().numpy(), e[p + "log_post"], rtol=1e-5, atol=2e-3)
+    assert rel_err(dact.view(D, B, 1), e[p + "g_act"]) < 1e-5
+    gq = e[p + "g_q_logits"]
+    assert np.allclose(res[H + 2 * D:H + 3 * D].numpy(), gq, rtol=1e-4, atol=1e-5 * np.abs(gq).max() + 1e-30)
+    assert np.allclose(float(res[4]), float(e[p + "g_log_std"][0]), rtol=1e-5, atol=1e-12)
+    ll_ref = -O.gauss_nll(act.double().view(D, B), y.double().view(1, B), ls.double())
+    assert rel_err(ll, ll_ref) < 1e-5
+
+
+@pytest.mark.parametrize("C", [10, 3, 100, 1000])
+def test_elbo_softmax_edges(be, C):
+    e = Case("edge")
+    p = "cls_%d/" % C
+    act, y, ql, N = e.t(p + "act"), e.t(p + "y").long(), e.t(p + "q_logits"), int(e[p + "N"])
+    D, B = act.shape[0], act.shape[1]
+    res, dact, ll, _ = _run_vi(be, act, y, False, ql, None, N)
+    H = 8
+    assert rel_err(res[H:H + D], e[p + "joint"]) < 1e-5
+    assert rel_err(res[0], e[p + "ELBO"]) < 1e-5
+    assert rel_err(res[3], e[p + "log_marg"]) < 1e-5
+    assert rel_err(dact, e[p + "g_act"]) < 1e-5
+    assert rel_err(res[H + 2 * D:H + 3 * D], e[p + "g_q_logits"]) < 1e-4
+    ll_ref = O.loglike_per_act(act.double(), y, False)
+    assert rel_err(ll, ll_ref) < 1e-5
+    # MLL: two passes, exact posterior as depth weights
+    logprior = torch.full((D,), 1.0 / D).log()
+    sums, _, _ = be.ll_pass(dev(act), dev(y), False, None, None, False, 1.0 / B, want_dact=False)
+    resm = be.depth_finalize(sums, False, None, dev(logprior), None, None, N, B, 1.0, 1e-35, 1)
+    _, dm, _ = be.ll_pass(dev(act), dev(y), False, None, resm[H + 3 * D:H + 4 * D], False, 1.0 / B)
+    assert rel_err(resm.cpu()[0], e[p + "log_marg"]) < 1e-5
+    assert rel_err(dm.cpu(), e[p + "gm_act"]) < 1e-5
+    # depth-marginal class probabilities + fused metrics
+    q = O.q_probs(ql)
+    probs, _, m = be.predict(dev(act), dev(q), False, y=dev(y))
+    assert rel_err(probs.cpu(), e[p + "probs"]) < 1e-5
+    pr = torch.from_numpy(e[p + "probs"])
+    nll_ref = -torch.log(pr.double()[torch.arange(B), y]).sum().item()
+    err_ref = float((pr.max(dim=1)[1] != y).sum())
+    m = m.cpu()
+    assert abs(m[0].item() - nll_ref) < 1e-5 * abs(nll_ref) and m[1].item() == err_ref
+
+
+@pytest.mark.parametrize("D,B", [(51, 65536), (11, 512), (3, 4099), (7, 1)])
+def test_elbo_gauss_sizes(be, D, B):
+    g = torch.Generator().manual_seed(D * 1000 + B)
+    act = torch.randn(D, B, 1, generator=g)
+    y = torch.randn(B, 1, generator=g)
+    ql, ls, N = 0.3 * torch.randn(D, generator=g), torch.tensor([0.1]), float(1 << 20)
+    res, dact, ll, _ = _run_vi(be, act, y, True, ql, ls, N)
+    logprior = torch.full((D,), 1.0 / D).log().double()
+    joint = O.joint_loglike(torch.zeros(D).double(), act.double(), y.double(), True, N, ls.double())
+    elbo = O.elbo(torch.zeros(D).double(), act.double(), y.double(), True, N, ql.double(), logprior, ls.double())
+    assert rel_err(res[8:8 + D], joint) < 1e-5 and rel_err(res[0], elbo) < 1e-5
+    cf = O.elbo_grads_closed_form(act.double(), y.double(), True, N, O.q_probs(ql.double()), log_std=ls.double(),
+                                  q_logits=ql.double(), logprior=logprior, prior_loglikes=torch.zeros(D).double())
+    assert rel_err(dact.view(D, B, 1), cf["dact"]) < 1e-5
+    assert rel_err(res[8 + 2 * D:8 + 3 * D], cf["dq_logits"]) < 1e-4
+    assert abs(float(res[4]) - float(cf["dlog_std"])) < 1e-5 * abs(float(cf["dlog_std"])) + 1e-9
+
+
+@pytest.mark.parametrize("tag", ["clamp", "peaked", "one_depth", "one_row"])
+def test_predict_gauss(be, tag):
+    e = Case("edge")
+    p = "reg_%s/" % tag
+    act, y, ls = e.t(p + "act"), e.t(p + "y"), e.t(p + "log_std")
+    q = torch.from_numpy(e[p + "q"])
+    mean, std, m = be.predict(dev(act), dev(q), True, get_std=True, y=dev(y), log_std=dev(ls))
+    assert rel_err(mean.cpu(), e[p + "mu"]) < 1e-5
+    assert np.allclose(std.cpu().numpy(), e[p + "std"], rtol=1e-3, atol=2e-4, equal_nan=True)
+    mu, sd = O.marginalise_predict(act.double(), q.double(), get_std=True)
+    ok = ~torch.isnan(sd).view(-1)
+    if bool(ok.all()) and not bool(torch.isnan(std).any()):
+        nll = O.gauss_nll(mu, y.double(), ls.double(), model_std=sd).sum().item()
+        se = ((mu - y.double()) ** 2).sum().item()
+        m = m.cpu()
+        assert abs(m[0].item() - nll) < 1e-4 * abs(nll) + 1e-6 and abs(m[1].item() - se) < 1e-5 * se + 1e-9
+
+
+# ------------------------------------------------------------------------------------------------------
+# shared head
+# ------------------------------------------------------------------------------------------------------
+def test_head_golden(be):
+    h = Case("head_c10")
+    feat, w, b = h.t("feat"), h.t("w"), h.t("b")
+    D, B, K = feat.shape
+    C = w.shape[0]
+    act = be.head_forward(dev(feat.view(D * B, K)), dev(w), dev(b))
+    assert rel_err(act.cpu().view(D, B, C), h["act"]) < 1e-5
+    y, ql, N = h.t("y").long(), h.t("q_logits"), int(h["N"])
+    res, dact, _, _ = _run_vi(be, act.view(D, B, C).cpu(), y, False, ql, None, N, want_ll=True)
+    assert rel_err(res[0], h["ELBO"]) < 1e-5
+    assert rel_err(res[8 + 2 * D:8 + 3 * D], h["g_q_logits"]) < 1e-4
+    dw, db, dH = be.head_backward(dev(feat.view(D * B, K)), dev(w), dev(dact.view(D * B, C)), need_dH=True)
+    assert rel_err(dw.cpu(), h["g_w"]) < 2e-5
+    assert rel_err(db.cpu(), h["g_b"]) < 2e-5
+    assert rel_err(dH.cpu().view(D, B, K), h["g_feat"]) < 2e-5
+
+
+@pytest.mark.parametrize("rows,K,O", [(5000, 2048, 1), (3000, 100, 1), (700, 50, 2), (1500, 512, 10), (300, 64, 20)])
+def test_head_shapes(be, rows, K, O):
+    g = torch.Generator().manual_seed(rows + K + O)
+    H, w, b = torch.randn(rows, K, generator=g), torch.randn(O, K, generator=g), torch.randn(O, generator=g)
+    dact = torch.randn(rows, O, generator=g)
+    act = be.head_forward(dev(H), dev(w), dev(b)).cpu()
+    ref = H.double() @ w.double().t() + b.double()
+    assert (act.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    dw, db, dH = be.head_backward(dev(H), dev(w), dev(dact), need_dH=True)
+    assert rel_err(dw.cpu(), dact.double().t() @ H.double()) < 1e-5
+    assert rel_err(db.cpu(), dact.double().sum(0)) < 1e-5
+    assert rel_err(dH.cpu(), dact.double() @ w.double()) < 1e-5
+
+
+def test_sgd_matches_torch(be):
+    g = torch.Generator().manual_seed(3)
+    n = 10007
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) for _ in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.05, momentum=0.9, weight_decay=1e-3)
+    p, buf = dev(p0.clone()), torch.zeros(n, device="cuda")
+    for gr in grads:
+        ref.grad = gr.clone()
+        opt.step()
+        be.sgd_step(p, dev(gr), buf, 0.05, 0.9, 1e-3)
+    assert rel_err(p.cpu(), ref.data) < 1e-6
+
+
+def test_errors_are_loud(be):
+    with pytest.raises(RuntimeError):
+        be.ll_pass(torch.zeros(2, 3, 1), torch.zeros(3, 1), True, torch.zeros(1), None, False, 1.0)  # CPU tensors
+    with pytest.raises(RuntimeError):
+        be.ll_pass(dev(torch.zeros(3, 5, 2)), dev(torch.zeros(5, 2)), True, dev(torch.zeros(2)), None, False, 1.0)
+    with pytest.raises(RuntimeError):
+        be.ll_pass(dev(torch.zeros(2, 3, 2000)), dev(torch.zeros(3).long()), False, None, None, False, 1.0)

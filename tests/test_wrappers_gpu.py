@@ -1,0 +1,221 @@
+"""GPU parity of the drop-in API (models + probability module + DUN / DUN_VI wrappers) against the golden
+vectors the real reference produced, and against an fp64 evaluation of the oracle where fp32 is noisy."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dun_oracle as O
+from tests.util import Case, FC_CASES, rel_err, stacked_grads_from_reference
+
+pytestmark = pytest.mark.gpu
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def build_net(c):
+    """dun_amd wrapper in the exact state the golden case started from."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from dun_amd.probability import depth_categorical, depth_categorical_VI
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_MLP, arq_uncert_fc_resnet
+    from dun_amd.training_wrappers import DUN, DUN_VI
+    cfg = c.cfg
+    ctor = arq_uncert_fc_MLP if cfg.get("mlp") else arq_uncert_fc_resnet
+    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"], w_prior=None, BMA_prior=False)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in c.sub("sd/").items()}
+    model.load_state_dict(sd)
+    if cfg["vi"]:
+        pm = depth_categorical_VI(c.prior(), cuda=True)
+        cls = DUN_VI
+    else:
+        pm = depth_categorical(c.prior(), cuda=True)
+        cls = DUN
+    net = quiet(cls, model, pm, cfg["N"], lr=cfg["lr"], momentum=cfg["momentum"], weight_decay=cfg["wd"],
+                cuda=True, regression=cfg["regression"], pred_sig=cfg.get("pred_sig"))
+    if cfg["vi"]:
+        pm.q_logits.data.copy_(c.t("q_logits0"))
+    if cfg["regression"]:
+        net.f_neg_loglike.log_std.data.copy_(c.t("log_std0"))
+    return net
+
+
+def noise_bounded(got32, ref32, truth64, slack=4.0, floor=3e-6):
+    return rel_err(got32, truth64) <= slack * rel_err(ref32, truth64) + floor
+
+
+def oracle64(c):
+    net = c.oracle_net(torch.float64)
+    x = c.t("x").double()
+    y = c.y() if not c.cfg["regression"] else c.y().double()
+    return net, x, y
+
+
+@pytest.mark.parametrize("name", FC_CASES)
+def test_forward_and_objective(name):
+    c = Case(name)
+    cfg = c.cfg
+    net = build_net(c)
+    x, y = c.t("x").cuda(), c.y().cuda()
+    net.model.train()
+    act = net.model.forward(x)
+    o64, x64, y64 = oracle64(c)
+    p64 = O.clone_params(o64.p)
+    act64 = O.fc_forward(p64, x64, train=True, residual=not cfg.get("mlp", False))
+    assert noise_bounded(act.detach().cpu(), c["act_vec"], act64)
+    # BatchNorm running statistics after one train-mode forward
+    for i in range(cfg["L"]):
+        assert rel_err(net.model.running_mean[i].cpu(), p64["running_mean"][i]) < 1e-5
+        assert rel_err(net.model.running_var[i].cpu(), p64["running_var"][i]) < 1e-5
+    assert int(net.model.num_batches_tracked.sum()) == cfg["L"]
+    prior = net.model.get_w_prior_loglike(k=None)
+    if cfg["vi"]:
+        out, ll = net.prob_model.fused_objective(prior, act, y, net.f_neg_loglike, cfg["N"], want_ll=True)
+        assert rel_err(out.objective.cpu(), c["ELBO"]) < 1e-5
+        assert rel_err(out.weights.cpu(), c["q"]) < 1e-5
+        assert abs(float(out.KL) - float(c["KL"])) < 1e-5
+        assert rel_err(out.E_loglike.cpu(), c["E_loglike"]) < 1e-5
+        # the reference-named differentiable entry gives the same number
+        elbo = net.prob_model.estimate_ELBO(prior, act.detach(), y, net.f_neg_loglike, cfg["N"], Beta=1)
+        assert rel_err(elbo.detach().cpu(), c["ELBO"]) < 1e-5
+    else:
+        out, ll = net.prob_model.fused_objective(prior, act, y, net.f_neg_loglike, cfg["N"], want_ll=True)
+        assert rel_err(out.objective.cpu(), c["log_marg"]) < 1e-5
+    # north-star parity bar: per-depth log-likelihoods within 1e-5 relative of the reference
+    assert rel_err(out.joint.cpu(), c["joint"]) < 1e-5
+    assert rel_err(ll.cpu().sum(dim=1), c["loglike"].sum(axis=1)) < 1e-5
+    ll64 = O.loglike_per_act(act64, y64, cfg["regression"], o64.log_std)
+    assert noise_bounded(ll.cpu(), c["loglike"], ll64)
+    assert rel_err(out.log_marg.cpu(), c["log_marg"]) < 1e-5
+    assert np.allclose(out.posterior.cpu().log().numpy(), c["log_post"], rtol=1e-4, atol=5e-3)
+    jl = net.prob_model.get_w_joint_loglike(prior, act.detach(), y, net.f_neg_loglike, cfg["N"])
+    assert rel_err(jl.cpu(), c["joint"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", FC_CASES)
+def test_gradients(name):
+    c = Case(name)
+    cfg = c.cfg
+    net = build_net(c)
+    x, y = c.t("x").cuda(), c.y().cuda()
+    net.model.train()
+    act = net.model.forward(x)
+    prior = net.model.get_w_prior_loglike(k=None)
+    out = net.prob_model.fused_objective(prior, act, y, net.f_neg_loglike, cfg["N"])
+    assert rel_err(out.dact.cpu().view(c["g/act_vec"].shape), c["g/act_vec"]) < 2e-5
+    net._backward(act, prior, out)
+    o64, x64, y64 = oracle64(c)
+    _, g64, _, _ = o64.fit(x64, y64, return_grads=True)
+    ref = stacked_grads_from_reference(c)
+    for k, v in ref.items():
+        assert noise_bounded(net.model.stacked_grad[k].cpu(), v, g64[k], slack=6.0), k
+    if cfg["vi"]:
+        assert noise_bounded(net.prob_model.q_logits.grad.cpu(), c["g/q_logits"], g64["q_logits"], floor=2e-5)
+    if cfg["regression"] and cfg.get("pred_sig") is None:
+        assert noise_bounded(net.f_neg_loglike.log_std.grad.cpu(), c["g/log_std"], g64["log_std"])
+    # the autograd route (estimate_ELBO / get_marg_loglike + loss.backward()) lands on the same gradients
+    net2 = build_net(c)
+    net2.model.train()
+    act2 = net2.model.forward(x)
+    prior2 = net2.model.get_w_prior_loglike(k=None)
+    if cfg["vi"]:
+        obj = net2.prob_model.estimate_ELBO(prior2, act2, y, net2.f_neg_loglike, cfg["N"], Beta=1)
+    else:
+        joint = net2.prob_model.get_w_joint_loglike(prior2, act2, y, net2.f_neg_loglike, cfg["N"])
+        obj = net2.prob_model.get_marg_loglike(joint)
+    (-obj / cfg["N"]).backward()
+    for k in ref:
+        a, b = net2.model.stacked_grad[k].cpu(), net.model.stacked_grad[k].cpu()
+        assert noise_bounded(a, b, g64[k], slack=6.0), k
+    if cfg["vi"]:
+        assert rel_err(net2.prob_model.q_logits.grad.cpu(), net.prob_model.q_logits.grad.cpu()) < 1e-4
+    if cfg["regression"] and cfg.get("pred_sig") is None:
+        assert rel_err(net2.f_neg_loglike.log_std.grad.cpu(), net.f_neg_loglike.log_std.grad.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("name", FC_CASES)
+def test_fit_eval_predict(name):
+    c = Case(name)
+    cfg = c.cfg
+    net = build_net(c)
+    x, y = c.t("x"), c.y()
+    for step in range(3):
+        ret = net.fit(x, y)
+        rt = 2e-5 if step == 0 else 5e-4
+        assert np.allclose(ret, c["fit/ret"][step], rtol=rt, atol=1e-6), (step, ret, c["fit/ret"][step])
+        assert np.allclose(net.prob_model.current_posterior.cpu().numpy(), c["fit/posterior"][step], rtol=2e-4,
+                           atol=1e-7)
+    sd = c.sub("fit/sd/")
+    got = net.model.state_dict()
+    for k in ("input_layer.weight", "output_layer.weight", "output_layer.bias"):
+        assert rel_err(got[k].cpu(), sd[k]) < 2e-4, k
+    for i in range(cfg["L"]):
+        for suffix in ("block.0.weight", "block.2.weight", "block.2.running_mean", "block.2.running_var"):
+            k = "stochstic_layers.%d.%s" % (i, suffix)
+            assert rel_err(got[k].cpu(), sd[k]) < 2e-4, k
+        assert int(got["stochstic_layers.%d.block.2.num_batches_tracked" % i]) == 3
+    if cfg["vi"]:
+        assert rel_err(net.prob_model.q_logits.data.cpu(), c["fit/q_logits"]) < 2e-4
+    if cfg["regression"]:
+        assert rel_err(net.f_neg_loglike.log_std.data.cpu(), c["fit/log_std"]) < 2e-4
+    assert np.allclose(net.eval(x, y), c["eval/ret"], rtol=5e-4)
+    xt = c.t("x_test")
+    assert rel_err(net.layer_predict(xt).cpu(), c["layer_predict"]) < 5e-4
+    if cfg["regression"]:
+        mu, std = net.predict(xt, get_std=True)
+        assert rel_err(mu.cpu(), c["pred/mu"]) < 5e-4 and rel_err(std.cpu(), c["pred/std"]) < 5e-4
+        _, mstd = net.predict(xt, get_std=True, return_model_std=True)
+        assert np.allclose(mstd.cpu().numpy(), c["pred/model_std"], rtol=5e-3, atol=1e-4, equal_nan=True)
+        assert rel_err(net.predict(xt).cpu(), c["pred/plain"]) < 5e-4
+        if c.has("pred/depth_k"):
+            k = int(c["pred/depth_k"])
+            net.prob_model.current_posterior = c.t("pred/depth_k_q").cuda()
+            mu, _ = net.predict(xt, depth=k, get_std=True, return_model_std=True)
+            assert rel_err(mu.cpu(), c["pred/depth_k_mu"]) < 5e-4
+    else:
+        assert rel_err(net.predict(xt).cpu(), c["pred/plain"]) < 5e-4
+    if cfg.get("sweep"):
+        bs, N = int(c["sweep/batch"]), cfg["N"]
+        ds = torch.utils.data.TensorDataset(x[:N], y[:N])
+        loader = torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=False)
+        post, lm = net.get_exact_d_posterior(loader, train_bn=False, logposterior=False)
+        assert np.allclose(post.cpu().numpy(), c["sweep/posterior"], rtol=2e-3, atol=1e-6)
+        assert abs(lm - float(c["sweep/log_marg"])) < 5e-4 * abs(lm)
+        if cfg["vi"]:
+            assert abs(net.get_exact_ELBO(loader) - float(c["sweep/ELBO"])) < 5e-4 * abs(float(c["sweep/ELBO"]))
+
+
+def test_seed_matched_construction_and_checkpoint(tmp_path):
+    """Same torch seed + same construction order as the reference => same initial weights (c1 fixture holds the
+    reference's state_dict for seed 0, with BN affine/running stats overwritten afterwards)."""
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_resnet
+    c = Case("c1_wiggle")
+    torch.manual_seed(0)
+    m = arq_uncert_fc_resnet(1, 1, 100, 10)
+    sd = c.sub("sd/")
+    got = m.state_dict()
+    for k in ("input_layer.weight", "input_layer.bias", "output_layer.weight", "stochstic_layers.9.block.0.weight"):
+        assert np.array_equal(got[k].numpy(), sd[k]), k
+    assert set(got.keys()) == set(sd.keys())
+    net = build_net(c)
+    net.fit(c.t("x"), c.y())
+    f = str(tmp_path / "theta.dat")
+    quiet(net.save, f)
+    net2 = build_net(c)
+    quiet(net2.load, f)
+    a, b = net.predict(c.t("x")), net2.predict(c.t("x"))
+    assert torch.equal(a, b)
+    r1, r2 = net.fit(c.t("x"), c.y()), net2.fit(c.t("x"), c.y())
+    assert np.allclose(r1, r2, rtol=1e-6)
+
+
+def test_o2_regression_raises_like_the_reference():
+    from dun_amd.probability import depth_categorical, homo_Gauss_mloglike
+    with pytest.raises(RuntimeError):
+        depth_categorical.get_w_joint_loglike(torch.zeros(3).cuda(), torch.randn(3, 5, 2).cuda(),
+                                              torch.randn(5, 2).cuda(), homo_Gauss_mloglike(2).cuda(), 10)
