@@ -115,6 +115,8 @@ def check(rc, what=""):
 
 
 def stream_ptr(device=None):
+    if device is not None and torch.device(device).type != "cuda":
+        raise RuntimeError("dun_amd kernels need GPU tensors (got device %s); there is no CPU path" % device)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -194,14 +194,16 @@ __global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __rest
     se = wave_sum(se);
     const double log_marg = mx + log(se);
 
-    double qmx = -INFINITY, qs = 0.0;
+    // q = softmax(q_logits) and log q = log_softmax(q_logits) in fp32, exactly the arithmetic the reference's
+    // F.softmax / F.log_softmax do: a q_d that underflows to 0 there is 0 here (and gets the eps clamp).
+    float qmx = -INFINITY, qs = 0.f;
     if (objective == DUN_OBJ_VI) {
-        for (int d = lane; d < D; d += 64) qmx = fmax(qmx, (double)q_logits[d]);
+        for (int d = lane; d < D; d += 64) qmx = fmaxf(qmx, q_logits[d]);
         qmx = wave_max(qmx);
-        for (int d = lane; d < D; d += 64) qs += exp((double)q_logits[d] - qmx);
+        for (int d = lane; d < D; d += 64) qs += expf(q_logits[d] - qmx);
         qs = wave_sum(qs);
     }
-    const double log_qs = log(qs);
+    const float log_qs = logf(qs);
 
     double E = 0.0, KL = 0.0, Asum = 0.0, Csum = 0.0, dls = 0.0;
     for (int d = lane; d < D; d += 64) {
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __rest
         post_o[d] = (float)post;
         double wgt = post;
         if (objective == DUN_OBJ_VI) {
-            const double lq = (double)q_logits[d] - qmx - log_qs;
-            const double q = exp(lq);
+            const double lq = (double)((q_logits[d] - qmx) - log_qs);
+            const double q = (double)(expf(q_logits[d] - qmx) / qs);
             const double c = fmin(fmax(q, eps), 1.0 - eps);
             const double m = (q >= eps && q <= 1.0 - eps) ? 1.0 : 0.0;
             E += q * J;
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __rest
             const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
             const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
             const double lp = (double)logprior[d];
-            const double lq = (double)q_logits[d] - qmx - log_qs;
-            const double q = exp(lq);
+            const double lq = (double)((q_logits[d] - qmx) - log_qs);
+            const double q = (double)(expf(q_logits[d] - qmx) / qs);
             const double c = fmin(fmax(q, eps), 1.0 - eps);
             const double m = (q >= eps && q <= 1.0 - eps) ? 1.0 : 0.0;
             const double dKL = m * q * (lq - lp) - q * Asum + c - q * Csum;
@@ -259,6 +261,12 @@ __global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __rest
 }
 
 // ---- depth-marginal prediction ----
+// value of an fp32 expression, rounded here: the empty asm makes it opaque, so it cannot become one half of an FMA
+__device__ __forceinline__ float rounded(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restrict__ act, const float* __restrict__ q,
                                                             int D, int n, float* __restrict__ mean,
@@ -282,16 +290,20 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (idx + e < n) ? a[e] : 0.f;
             }
+            // every product rounded on its own, as (q * preds).sum(0) and (q * preds**2).sum(0) do in the
+            // reference: an FMA here would make var = sum(q a^2) - mu^2 come out slightly negative (-> NaN std)
+            // where the reference gets exactly 0 (one-hot posteriors, single depth)
+            // (hipcc contracts a*b+c into an FMA by default, through __fmul_rn too: rounded() hides each product)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                mu[e] += qd * v[e];
-                m2[e] += qd * (v[e] * v[e]);
+                mu[e] += rounded(qd * v[e]);
+                m2[e] += rounded(qd * rounded(v[e] * v[e]));
             }
         }
     }
     float sd[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sd[e] = sqrtf(m2[e] - mu[e] * mu[e]);  // NaN for a negative variance, as pow(0.5)
+    for (int e = 0; e < 4; ++e) sd[e] = sqrtf(m2[e] - rounded(mu[e] * mu[e]));  // NaN if negative, as pow(0.5)
     double nll = 0.0, se = 0.0;
     if (any) {
 #pragma unroll

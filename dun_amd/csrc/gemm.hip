@@ -36,7 +36,7 @@ struct GemmP {
     const float* U;
     const float* V;
     int O, ldv;
-    float* colstats;
+    double* colstats;
     int gridM, gridN;
 };
 
@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
 
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    // BatchNorm statistics are accumulated in fp64 from the first element on: sum z^2 - (sum z)^2/n in fp32
+    // loses the variance of a nearly constant column (narrow inputs make many of those), and the reference's
+    // batch_norm uses a cancellation-free update.  64 dfma per lane per tile: free next to the K loop.
+    double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = n0 + wc * 64 + ni * 32 + li;
@@ -195,14 +198,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
                         for (int o = 0; o < p.O; ++o) v += p.U[(size_t)row * p.O + o] * p.V[(size_t)o * p.ldv + col];
                     }
                     p.C[(size_t)row * p.ldc + col] = v;
-                    s1[ni] += v;
-                    s2[ni] += v * v;
+                    if (p.colstats != nullptr) {
+                        const double dv = (double)v;
+                        s1[ni] += dv;
+                        s2[ni] += dv * dv;
+                    }
                 }
             }
         }
     }
     if (p.colstats != nullptr) {
-        float* red = smem;  // all waves are past the last barrier of the main loop: LDS is free
+        double* red = reinterpret_cast<double*>(smem);  // all waves are past the last barrier: LDS is free
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             s1[ni] += __shfl_xor(s1[ni], 32, 64);
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         if (tid < BN) {
             const int wc2 = tid >> 6, ni2 = (tid >> 5) & 1, l2 = tid & 31, col = n0 + tid;
             if (col < p.N) {
-                float t1 = 0.f, t2 = 0.f;
+                double t1 = 0.0, t2 = 0.0;
 #pragma unroll
                 for (int w2 = 0; w2 < 2; ++w2) {
                     const int wv = w2 * 2 + wc2;

@@ -46,7 +46,8 @@ struct Vec<1> {
 
 // out_d[a][c] = sum_p partials[a][p][c] (fp64, fixed order); optional float copies per array.
 // workgroup = 64 columns x 4 partial-lanes.
-__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ partials, int P, int W,
+template <typename PT>
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const PT* __restrict__ partials, int P, int W,
                                                           double* __restrict__ out_d, float* __restrict__ out_f0,
                                                           float* __restrict__ out_f1) {
     __shared__ double red[RY][CX];
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restric
     const int c = blockIdx.x * CX + tx, a = blockIdx.y;
     double s = 0.0;
     if (c < W) {
-        const float* src = partials + (size_t)a * P * W + c;
+        const PT* src = partials + (size_t)a * P * W + c;
         for (int p = ty; p < P; p += RY) s += (double)src[(size_t)p * W];
     }
     red[ty][tx] = s;
@@ -96,12 +97,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int tx = threadIdx.x & (CX - 1), ty = threadIdx.x >> 6;
     const int c = (blockIdx.x * CX + tx) * VW;
     if (c >= W) return;
-    float sc[VW], sh[VW];
+    // (z - mean) first, then scale: folding the mean into a single fma offset (z*sc + (beta - mean*sc)) loses
+    // the low bits of every column whose spread is small next to its mean
+    float sc[VW], mu[VW], sh[VW];
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
         const float rs = stat_is_var ? 1.f / sqrtf(rstd[c + e] + eps) : rstd[c + e];
         sc[e] = gamma[c + e] * rs;
-        sh[e] = beta[c + e] - mean[c + e] * sc[e];
+        mu[e] = mean[c + e];
+        sh[e] = beta[c + e];
     }
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(B, r0 + rows_per_block);
@@ -112,10 +116,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         if (residual) {
             typename V::T hi = V::load(Hin + off);
 #pragma unroll
-            for (int e = 0; e < VW; ++e) V::set(o, e, V::get(hi, e) + (V::get(z, e) * sc[e] + sh[e]));
+            for (int e = 0; e < VW; ++e) V::set(o, e, V::get(hi, e) + ((V::get(z, e) - mu[e]) * sc[e] + sh[e]));
         } else {
 #pragma unroll
-            for (int e = 0; e < VW; ++e) V::set(o, e, V::get(z, e) * sc[e] + sh[e]);
+            for (int e = 0; e < VW; ++e) V::set(o, e, (V::get(z, e) - mu[e]) * sc[e] + sh[e]);
         }
         V::store(Hout + off, o);
     }
@@ -314,6 +318,7 @@ static int check_ctx(const dun_fc_ctx* c, const char* who) {
     DUN_REQUIRE(c->depth == 0 || c->Z, "%s: null Z", who);
     DUN_REQUIRE(c->ws && c->ws_floats >= dun_fc_workspace_floats(c->B, c->din, c->W, c->O, c->L),
                 "%s: workspace too small", who);
+    DUN_REQUIRE(aligned16(c->ws), "%s: workspace must be 16-byte aligned", who);
     DUN_REQUIRE(!c->train || c->depth == 0 || (c->bn_mean && c->bn_rstd && c->bn_sums), "%s: train mode needs bn_mean/bn_rstd/bn_sums", who);
     return DUN_OK;
 }
@@ -349,12 +354,13 @@ static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s) {
     g.M = c->B; g.N = W; g.K = W;
     g.bias = c->p.b + (size_t)i * W;
     g.relu = 1;
-    g.colstats = c->train ? c->ws : nullptr;
+    double* stats = reinterpret_cast<double*>(c->ws);  // ws is 16-byte aligned (checked in check_ctx)
+    g.colstats = c->train ? stats : nullptr;
     int rc = gemm_f32(&g, s);
     if (rc) return rc;
     if (c->train) {
-        hipLaunchKernelGGL(reduce_cols_kernel, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, c->ws, P, W, c->bn_sums,
-                           (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(reduce_cols_kernel<double>, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, stats, P, W,
+                           c->bn_sums, (float*)nullptr, (float*)nullptr);
         DUN_LAUNCH_CHECK();
     }
     return DUN_OK;
@@ -440,7 +446,7 @@ static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
                            P, c->ws);
     DUN_LAUNCH_CHECK();
     // local sums are this rank's dbeta / dgamma; the fp64 copy is what a sharded job all-reduces
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, c->ws, P, W, c->bn_sums,
+    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, c->ws, P, W, c->bn_sums,
                        c->g.beta + (size_t)i * W, c->g.gamma + (size_t)i * W);
     DUN_LAUNCH_CHECK();
     return DUN_OK;
@@ -459,8 +465,8 @@ static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipS
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, Z, mean, rstd, gamma,
                            c->bn_sums, global_batch, B, W, c->dU, c->ws);
     DUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W, (double*)nullptr,
-                       c->g.b + (size_t)i * W, (float*)nullptr);
+    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W,
+                       (double*)nullptr, c->g.b + (size_t)i * W, (float*)nullptr);
     DUN_LAUNCH_CHECK();
     // dW_i[n_out, k_in] = sum_b dU[b, n_out] * H_i[b, k_in]
     dun_gemm_desc g;
@@ -498,8 +504,8 @@ static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
     else
         hipLaunchKernelGGL(colsum_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, B, W, c->ws);
     DUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_cols_kernel, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W, (double*)nullptr,
-                       c->g.b_in, (float*)nullptr);
+    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W,
+                       (double*)nullptr, c->g.b_in, (float*)nullptr);
     DUN_LAUNCH_CHECK();
     return DUN_OK;
 }
@@ -511,7 +517,7 @@ using namespace dun;
 extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
     (void)din;
     const size_t P = (size_t)num_slabs(B);
-    const size_t cols = 2 * P * (size_t)W;
+    const size_t cols = 4 * P * (size_t)W;  // fp64 [2][P][W] forward statistics partials
     const size_t hb = head_backward_ws((L + 1) * B, W, O);
     return (cols > hb ? cols : hb) + 64;
 }

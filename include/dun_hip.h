@@ -118,7 +118,7 @@ typedef struct dun_gemm_desc {
     const float* U;    /* rank-O update: C += U[m*O + o] * V[o*ldv + n]; NULL for none */
     const float* V;
     int O, ldv;
-    float* colstats;   /* NULL, or [2][ceil(M/128)][N]: per 128-row tile column sums of C and C^2 */
+    double* colstats;  /* NULL, or fp64 [2][ceil(M/128)][N]: per 128-row tile column sums of C and C^2 */
 } dun_gemm_desc;
 int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream);
 

@@ -75,3 +75,42 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     denom = max(np.abs(b).max(), 1e-30)
     return float(np.abs(a - b).max() / denom)
+
+
+def oracle_grads_with_masks(case, masks, dtype=torch.float64):
+    """Gradients of the case's loss from an fp64 evaluation of the oracle in which every ReLU uses the given
+    activation pattern (masks [L,B,W], bool).  fp32 implementations legitimately disagree on the sign of
+    pre-activations within rounding noise of zero; one such flip moves a weight gradient by O(1/B), far above
+    fp32 rounding.  Forcing the pattern isolates the arithmetic under test from that coin toss."""
+    import torch.nn.functional as F
+    cfg = case.cfg
+    net = case.oracle_net(dtype)
+    p = net.p
+    leaves = {k: p[k] for k in O.PARAM_KEYS}
+    if cfg["vi"]:
+        leaves["q_logits"] = net.q_logits
+    if cfg["regression"] and cfg.get("pred_sig") is None:
+        leaves["log_std"] = net.log_std
+    for v in leaves.values():
+        v.requires_grad_(True)
+    x = case.t("x").to(dtype)
+    y = case.y() if not cfg["regression"] else case.y().to(dtype)
+    residual = not cfg.get("mlp", False)
+    h = F.linear(x, p["w_in"], p["b_in"])
+    acts = [F.linear(h, p["w_out"], p["b_out"])]
+    for i in range(cfg["L"]):
+        u = F.linear(h, p["w"][i], p["b"][i])
+        z = u * masks[i].to(dtype)
+        m, v = z.mean(0), z.var(0, unbiased=False)
+        blk = (z - m) / torch.sqrt(v + 1e-5) * p["gamma"][i] + p["beta"][i]
+        h = h + blk if residual else blk
+        acts.append(F.linear(h, p["w_out"], p["b_out"]))
+    act_vec = torch.stack(acts)
+    D = cfg["L"] + 1
+    joint = O.joint_loglike(torch.zeros(D, dtype=dtype), act_vec, y, cfg["regression"], cfg["N"], net.log_std)
+    if cfg["vi"]:
+        obj = (O.q_probs(net.q_logits) * joint).sum() - O.kl_q_prior(net.q_logits, net.logprior)
+    else:
+        obj = O.marg_loglike(joint, net.logprior)
+    grads = torch.autograd.grad(-obj / cfg["N"], list(leaves.values()))
+    return dict(zip(leaves.keys(), grads)), act_vec.detach()
