@@ -58,6 +58,18 @@ class Shard(object):
 def shard(net, group=None, sync_bn=True, overlap=True):
     """Make a DUN / DUN_VI wrapper train on this rank's shard of every global batch."""
     spec = Shard(group, sync_bn=sync_bn, overlap=overlap)
+    # replicas must start identical: rank 0's parameters, BatchNorm buffers, q_logits and log_std win
+    with torch.no_grad():
+        tensors = [p.data for p in net.model.parameters() if getattr(p, "_dun_flat_owner", None) is None]
+        tensors += [b for b in net.model.buffers() if getattr(net.model, "flat_params", None) is None]
+        if getattr(net.model, "flat_params", None) is not None:
+            tensors += [net.model.flat_params, net.model.running_mean, net.model.running_var,
+                        net.model.num_batches_tracked]
+        tensors += [p.data for p in net.prob_model.parameters()]
+        tensors += [p.data for p in net.f_neg_loglike.parameters()]
+        if spec.world > 1:
+            for t in tensors:
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     net.model._dist = spec
     net.prob_model._dist = spec
     net._dist = spec

@@ -1,0 +1,106 @@
+"""world_size-2 gloo test of the batch-sharded path (CPU stand-in backend): two ranks, each on half the rows of a
+global batch, must reproduce the single-process step on the full batch -- objective, metrics, parameters, BatchNorm
+running statistics -- with synchronised BatchNorm; and must differ with per-replica statistics."""
+import contextlib
+import io
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.util import Case
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _net(case):
+    from dun_amd import kernels
+    from tests.cpu_backend import CpuBackend
+    from tests.test_host_cpu import build_cpu_net
+    kernels.set_backend(CpuBackend())
+    return build_cpu_net(case)
+
+
+def _state(net):
+    out = {"flat": net.model.flat_params.clone(), "rm": net.model.running_mean.clone(),
+           "rv": net.model.running_var.clone()}
+    if hasattr(net.prob_model, "q_logits"):
+        out["q"] = net.prob_model.q_logits.data.clone()
+    if net.regression:
+        out["ls"] = net.f_neg_loglike.log_std.data.clone()
+    return out
+
+
+def _worker(rank, world, port, name, sync_bn, steps, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dun_amd.distributed import shard
+        c = Case(name)
+        net = _net(c)
+        if rank == 1:  # replicas may start different: shard() must broadcast rank 0's state
+            net.model.flat_params.add_(0.5)
+        with contextlib.redirect_stdout(io.StringIO()):
+            shard(net, sync_bn=sync_bn)
+        x, y = c.t("x"), c.y()
+        B = x.shape[0] // world
+        xs, ys = x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B]
+        rets = [net.fit(xs, ys) for _ in range(steps)]
+        ev = net.eval(xs, ys)
+        st = _state(net)
+        ret[rank] = (rets, ev, {k: v.numpy() for k, v in st.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(name, sync_bn, steps=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, name, sync_bn, steps, ret), nprocs=2, join=True)
+    return ret[0], ret[1]
+
+
+def _single(name, steps=2):
+    c = Case(name)
+    net = _net(c)
+    x, y = c.t("x"), c.y()
+    rets = [net.fit(x, y) for _ in range(steps)]
+    ev = net.eval(x, y)
+    from dun_amd import kernels
+    kernels.set_backend(None)
+    return rets, ev, {k: v.numpy() for k, v in _state(net).items()}
+
+
+@pytest.mark.parametrize("name", ["c3_reduced", "cls_fc", "mll_small"])
+def test_two_ranks_match_single_process(name):
+    r0, r1 = _run(name, sync_bn=True)
+    rets, ev, st = _single(name)
+    for (a, b, s) in zip(r0[0], r1[0], rets):
+        assert np.allclose(a, b, rtol=1e-6, equal_nan=True)          # both ranks report the global-batch metrics
+        assert np.allclose(a, s, rtol=2e-5, atol=1e-6, equal_nan=True), (a, s)
+    assert np.allclose(r0[1], ev, rtol=2e-5, equal_nan=True)
+    for k in st:
+        assert np.allclose(r0[2][k], r1[2][k], rtol=0, atol=0), k        # replicas stay bit-identical
+        scale = np.abs(st[k]).max()
+        assert np.abs(r0[2][k] - st[k]).max() <= 2e-5 * scale + 1e-7, k
+
+
+def test_per_replica_batchnorm_differs():
+    r0, _ = _run("c3_reduced", sync_bn=False, steps=1)
+    rets, _, st = _single("c3_reduced", steps=1)
+    # per-replica statistics are a different (DataParallel-like) computation: close, but not the same numbers
+    assert abs(r0[0][0][0] - rets[0][0]) > 1e-6 * abs(rets[0][0])
+    assert np.abs(r0[2]["rm"] - st["rm"]).max() > 0

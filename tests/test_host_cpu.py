@@ -1,0 +1,133 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/dun_hip.h declares; the host logic above the
+ABI (wrappers, optimizer, autograd plumbing) reproduces the reference's goldens when driven by the CPU stand-in
+backend; and the product backend refuses CPU tensors instead of falling back."""
+import contextlib
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import Case, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_library_exports_every_declared_symbol():
+    from dun_amd import _lib
+    from dun_amd.build import build_library
+    lib = ctypes.CDLL(build_library())
+    header = open(os.path.join(ROOT, "include", "dun_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(dun_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libdun_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.dun_abi_version() >= 1
+
+
+def test_no_cpu_fallback_in_product_backend():
+    from dun_amd import kernels
+    kernels.set_backend(None)
+    be = kernels.backend()
+    assert be.name == "hip"
+    with pytest.raises(RuntimeError, match="GPU"):
+        be.ll_pass(torch.zeros(2, 3, 1), torch.zeros(3, 1), True, torch.zeros(1), None, False, 1.0)
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_resnet
+    m = arq_uncert_fc_resnet(3, 1, 8, 2)
+    with pytest.raises(RuntimeError):
+        m.forward(torch.zeros(4, 3))
+
+
+def test_argument_validation_without_gpu():
+    """Host-side validation of the C entries rejects bad arguments before anything is launched."""
+    from dun_amd import _lib as L
+    lib = L.lib()
+    assert lib.dun_ll_gauss(None, None, None, None, 0, 3, 5, 1.0, None, None, None, None) == 1
+    assert b"null" in lib.dun_last_error()
+    assert lib.dun_sgd_step(None, None, None, 10, 0.1, 0.9, 0.0, None) == 1
+    d = L.GemmDesc()
+    assert lib.dun_gemm_f32(ctypes.byref(d), None) == 1
+    assert lib.dun_ll_num_partials(65536, 1) == 16 and lib.dun_ll_num_partials(0, 1) == 0
+    assert lib.dun_fc_workspace_floats(512, 13, 100, 1, 10) > 0
+
+
+@pytest.fixture
+def cpu_backend():
+    from dun_amd import kernels
+    from tests.cpu_backend import CpuBackend
+    kernels.set_backend(CpuBackend())
+    yield
+    kernels.set_backend(None)
+
+
+def build_cpu_net(c):
+    from dun_amd.probability import depth_categorical, depth_categorical_VI
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_MLP, arq_uncert_fc_resnet
+    from dun_amd.training_wrappers import DUN, DUN_VI
+    cfg = c.cfg
+    ctor = arq_uncert_fc_MLP if cfg.get("mlp") else arq_uncert_fc_resnet
+    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"])
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in c.sub("sd/").items()})
+    pm = (depth_categorical_VI if cfg["vi"] else depth_categorical)(c.prior(), cuda=False)
+    net = quiet(DUN_VI if cfg["vi"] else DUN, model, pm, cfg["N"], lr=cfg["lr"], momentum=cfg["momentum"],
+                weight_decay=cfg["wd"], cuda=False, regression=cfg["regression"], pred_sig=cfg.get("pred_sig"))
+    if cfg["vi"]:
+        pm.q_logits.data.copy_(c.t("q_logits0"))
+    if cfg["regression"]:
+        net.f_neg_loglike.log_std.data.copy_(c.t("log_std0"))
+    return net
+
+
+@pytest.mark.parametrize("name", ["c2_boston", "mlp_nores", "fixed_sig", "cls_fc", "cls_fc_mll", "mll_small"])
+def test_host_logic_reproduces_goldens(cpu_backend, name):
+    c = Case(name)
+    cfg = c.cfg
+    net = build_cpu_net(c)
+    x, y = c.t("x"), c.y()
+    for step in range(3):
+        ret = np.array(net.fit(x, y))
+        want = c["fit/ret"][step]
+        keep = [0, 2] if np.isnan(ret[1]) else [0, 1, 2]
+        assert np.allclose(ret[keep], want[keep], rtol=2e-5 if step == 0 else 2e-3, atol=1e-6), (step, ret, want)
+    if cfg["vi"]:
+        assert rel_err(net.prob_model.q_logits.data, c["fit/q_logits"]) < 2e-3
+    sd = net.model.state_dict()
+    assert rel_err(sd["input_layer.weight"], c["fit/sd/input_layer.weight"]) < 2e-3
+    assert int(sd["stochstic_layers.0.block.2.num_batches_tracked"]) == 3
+    ev = np.array(net.eval(x, y))
+    keep = [1] if np.isnan(ev[0]) else [0, 1]
+    assert np.allclose(ev[keep], c["eval/ret"][keep], rtol=5e-3)
+    assert rel_err(net.predict(c.t("x_test")), c["pred/plain"]) < 5e-3
+    if cfg.get("sweep"):
+        bs, N = int(c["sweep/batch"]), cfg["N"]
+        loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x[:N], y[:N]), batch_size=bs)
+        post, lm = net.get_exact_d_posterior(loader)
+        assert abs(lm - float(c["sweep/log_marg"])) < 5e-3 * abs(lm)
+        if cfg["vi"]:
+            assert abs(net.get_exact_ELBO(loader) - float(c["sweep/ELBO"])) < 5e-3 * abs(float(c["sweep/ELBO"]))
+
+
+def test_q_warmup_and_scheduler(cpu_backend):
+    """Callers freeze q_logits for the first epochs (src/DUN/train_fc.py:51-57): a frozen q must not move."""
+    c = Case("c2_boston")
+    net = build_cpu_net(c)
+    q0 = net.prob_model.q_logits.data.clone()
+    net.prob_model.q_logits.requires_grad = False
+    net.fit(c.t("x"), c.y())
+    assert torch.equal(net.prob_model.q_logits.data, q0)
+    net.prob_model.q_logits.requires_grad = True
+    net.fit(c.t("x"), c.y())
+    assert not torch.equal(net.prob_model.q_logits.data, q0)
+    net.make_scheduler(gamma=0.1, milestones=[1])
+    net.update_lr()
+    assert abs(net.optimizer.param_groups[0]["lr"] - 0.1 * c.cfg["lr"]) < 1e-12 and net.epoch == 1

@@ -251,3 +251,31 @@ def test_o2_regression_raises_like_the_reference():
     with pytest.raises(RuntimeError):
         depth_categorical.get_w_joint_loglike(torch.zeros(3).cuda(), torch.randn(3, 5, 2).cuda(),
                                               torch.randn(5, 2).cuda(), homo_Gauss_mloglike(2).cuda(), 10)
+
+
+def test_sharded_path_world1_matches_unsharded():
+    """The staged C entries + torch.distributed(nccl = RCCL) plumbing at world size 1 must give exactly the numbers of
+    the fused single-call path (same kernels, same order)."""
+    import socket
+    import torch.distributed as dist
+    from dun_amd.distributed import shard
+    c = Case("c3_reduced")
+    x, y = c.t("x"), c.y()
+    ref = build_net(c)
+    want = [ref.fit(x, y) for _ in range(2)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        net = build_net(c)
+        quiet(shard, net, sync_bn=True)
+        got = [net.fit(x, y) for _ in range(2)]
+        assert np.allclose(got, want, rtol=1e-6)
+        assert torch.equal(net.model.flat_params, ref.model.flat_params)
+        assert torch.equal(net.model.running_var, ref.model.running_var)
+        assert np.allclose(net.eval(x, y), ref.eval(x, y), rtol=1e-6)
+    finally:
+        dist.destroy_process_group()
