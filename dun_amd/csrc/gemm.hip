@@ -154,6 +154,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         const float* b_s = a_s + TILE_FLOATS;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+            if (t == 2 && more) {
+                // stage tile kt+1 into the other buffer in the MIDDLE of this tile's MFMAs: the ds_writes (and the
+                // wait for the global loads issued ~2000 cycles ago) issue while the matrix pipe is busy, so the
+                // only thing left between the last MFMA and the barrier is the barrier itself.  Safe: every wave has
+                // passed the barrier that ended iteration kt-1, i.e. nobody reads buffer cur^1 any more.
+                float* nxt = smem + (cur ^ 1) * (2 * TILE_FLOATS);
+                store_tile<A_KC>(nxt, tid, ra);
+                store_tile<B_KC>(nxt + TILE_FLOATS, tid, rb);
+            }
             float a[2][4], b[2][4];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) read_frag<A_KC>(a_s, wr * 64 + mi * 32 + li, t, h, a[mi]);
@@ -166,11 +175,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
-        }
-        if (more) {
-            float* nxt = smem + (cur ^ 1) * (2 * TILE_FLOATS);
-            store_tile<A_KC>(nxt, tid, ra);
-            store_tile<B_KC>(nxt + TILE_FLOATS, tid, rb);
         }
         __syncthreads();
     }
