@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdun_hip.so")
+LIB_PATH = os.environ.get("DUN_HIP_LIB") or os.path.join(_HERE, "libdun_hip.so")
 
 DUN_OK = 0
 OBJ_VI, OBJ_MLL = 0, 1

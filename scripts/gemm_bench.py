@@ -1,0 +1,24 @@
+"""Micro-benchmark of the three trunk GEMM instantiations at the C3 shapes (GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dun_amd import kernels
+from bench import timed
+be = kernels.backend()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+W = 2048
+g = torch.Generator(device="cuda").manual_seed(0)
+H = torch.randn(B, W, device="cuda", generator=g)
+Z = torch.randn(B, W, device="cuda", generator=g)
+w = torch.randn(W, W, device="cuda", generator=g) * 0.02
+b = torch.randn(W, device="cuda", generator=g)
+out = torch.empty(B, W, device="cuda")
+gw = torch.empty(W, W, device="cuda")
+fl = 2.0 * B * W * W
+for rep in range(2):
+    ms = timed(lambda: be.gemm(H, w, B, W, W, bias=b, relu=True, colstats=True, out=out), 10)
+    print("fwd  %.3f ms  %.1f TF" % (ms, fl / ms / 1e9))
+    ms = timed(lambda: be.gemm(Z, w, B, W, W, a_kcontig=True, b_kcontig=False, R=out, out=out), 10)
+    print("dX   %.3f ms  %.1f TF" % (ms, fl / ms / 1e9))
+    ms = timed(lambda: be.gemm(Z, H, W, W, B, a_kcontig=False, b_kcontig=False, out=gw), 10)
+    print("dW   %.3f ms  %.1f TF" % (ms, fl / ms / 1e9), flush=True)

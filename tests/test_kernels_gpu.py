@@ -30,7 +30,9 @@ def dev(t):
 # fp32 MFMA GEMM
 # ------------------------------------------------------------------------------------------------------
 GEMM_SHAPES = [(128, 128, 32), (256, 384, 160), (300, 100, 100), (512, 100, 13), (300, 100, 1), (1, 1, 1),
-               (129, 257, 67), (1024, 256, 256), (100, 13, 512), (64, 2048, 96), (5, 3, 1000)]
+               (129, 257, 67), (1024, 256, 256), (100, 13, 512), (64, 2048, 96), (5, 3, 1000),
+               # tile-aligned problems take the LDS-DMA kernel (M%128 == N%128 == K%32 == 0)
+               (256, 256, 2048), (2048, 128, 64), (128, 2048, 4096)]
 
 
 @pytest.mark.parametrize("a_kc", [True, False])
