@@ -278,7 +278,68 @@ def head_case():
     print("wrote head_c10")
 
 
+def image_case():
+    """Reduced image DUN (C4/C5 family): ResNet-18 DUN on 16x16 inputs.  The 11 M weights are not stored: the
+    fixture pins the torch seed, and dun_amd's constructor draws its initial weights in the reference's order."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.DUN.stochastic_img_resnets import resnet18
+    for tag, kw, shape in (("img_r18", dict(start_depth=1, end_depth=7, num_classes=10, zero_init_residual=True,
+                                            initial_conv="1x3", concat_pool=False, input_chanels=3, p_drop=0),
+                            (6, 3, 16, 16)),
+                           ("img_r18_mnist", dict(start_depth=2, end_depth=4, num_classes=10, zero_init_residual=False,
+                                                  initial_conv="3x3", concat_pool=True, input_chanels=1, p_drop=0),
+                            (5, 1, 28, 28))):
+        torch.manual_seed(0)
+        model = resnet18(arch_uncert=True, **kw)
+        D = model.n_layers
+        g = torch.Generator().manual_seed(21)
+        x = torch.randn(*shape, generator=g)
+        y = torch.randint(0, 10, (shape[0],), generator=g)
+        pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=False)
+        pm.q_logits.data = 0.2 * torch.randn(D, generator=g)
+        net = quiet(DUN_VI, model, pm, 60000, lr=0.1, momentum=0.9, weight_decay=1e-4, cuda=False, regression=False)
+        out = {"meta": json.dumps(dict(kw=kw, shape=shape, D=D, N=60000, lr=0.1, momentum=0.9, wd=1e-4)),
+               "x": npy(x), "y": npy(y), "q_logits0": npy(pm.q_logits)}
+        out["n_params"] = np.array(sum(p.numel() for p in model.parameters()))
+        out["keys"] = np.array(sorted(model.state_dict().keys()))
+        # weight fingerprints (seed-matched construction check)
+        sd = model.state_dict()
+        for k in ("conv1.0.weight", "layer_list.0.conv1.weight", "layer_list.7.conv2.weight", "adapt0.0.weight",
+                  "adapt2.0.weight", "output_block.weight", "output_block.bias"):
+            out["w/" + k] = npy(sd[k]).ravel()[:64]
+        m2 = copy.deepcopy(model)
+        m2.train()
+        act = m2.forward(x)
+        act.retain_grad()
+        ELBO = pm.estimate_ELBO(m2.get_w_prior_loglike(), act, y, net.f_neg_loglike, net.N_train, Beta=1)
+        (-ELBO / net.N_train).backward()
+        out["act_vec"], out["ELBO"], out["g/act_vec"] = npy(act), npy(ELBO), npy(act.grad)
+        out["g/output_block.weight"] = npy(m2.output_block.weight.grad)
+        out["g/output_block.bias"] = npy(m2.output_block.bias.grad)
+        out["g/conv1.0.weight"] = npy(m2.conv1[0].weight.grad)
+        out["g/q_logits"] = npy(pm.q_logits.grad)
+        pm.q_logits.grad = None
+        m2.eval()
+        with torch.no_grad():
+            out["act_eval"] = npy(m2.forward(x))
+        rets = [net.fit(x, y) for _ in range(2)]
+        out["fit/ret"] = np.array(rets, dtype=np.float64)
+        out["fit/q_logits"] = npy(pm.q_logits)
+        out["eval/ret"] = np.array(net.eval(x, y), dtype=np.float64)
+        out["pred"] = npy(net.predict(x))
+        peaked = torch.zeros(D)
+        peaked[1], peaked[D - 1] = 0.7, 0.3
+        net.prob_model.current_posterior = peaked
+        out["fast_pred"] = npy(quiet(net.fast_predict, x))
+        out["fast_pred_q"] = npy(peaked)
+        np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+        print("wrote", tag, "fit ret", rets[-1], "D", D)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "image":
+        image_case()
+        return
     base = dict(seed=0, O=1, vi=True, regression=True, wd=0.0)
     X, Y = load_wiggle()
     run_case("c1_wiggle", dict(base, din=1, W=100, L=10, N=300, lr=1e-3, momentum=0.9, wd=1e-4, sweep=True),
@@ -304,6 +365,7 @@ def main():
                                 momentum=0.9), xc, yc)
     edge_cases()
     head_case()
+    image_case()
 
 
 if __name__ == "__main__":
