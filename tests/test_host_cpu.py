@@ -131,3 +131,36 @@ def test_q_warmup_and_scheduler(cpu_backend):
     net.make_scheduler(gamma=0.1, milestones=[1])
     net.update_lr()
     assert abs(net.optimizer.param_groups[0]["lr"] - 0.1 * c.cfg["lr"]) < 1e-12 and net.epoch == 1
+
+
+def test_train_fc_loop_plumbing(cpu_backend, tmp_path):
+    """Config-1 plumbing on CPU (stand-in backend): the epoch loop trains, tracks, checkpoints and stops early."""
+    from dun_amd.datasets import Datafeed, load_wiggle
+    from dun_amd.probability import depth_categorical_VI
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_resnet
+    from dun_amd.train_fc import train_fc_DUN
+    from dun_amd.training_wrappers import DUN_VI
+    from oracle.dun_oracle import wiggle_data
+    X, Y = load_wiggle()
+    Xo, Yo = wiggle_data()
+    assert np.array_equal(X, Xo) and np.array_equal(Y, Yo)
+    ds = Datafeed(torch.Tensor(X), torch.Tensor(Y))
+    train = torch.utils.data.DataLoader(ds, batch_size=128, shuffle=True)
+    val = torch.utils.data.DataLoader(ds, batch_size=128, shuffle=False)
+    torch.manual_seed(0)
+    model = arq_uncert_fc_resnet(1, 1, 24, 3)
+    net = quiet(DUN_VI, model, depth_categorical_VI([0.25] * 4, cuda=False), 300, lr=1e-2, momentum=0.9, cuda=False,
+                regression=True, weight_decay=1e-4)
+    out = quiet(train_fc_DUN, net, "t", str(tmp_path), 128, 6, train, val, False, seed=0, nb_its_dev=2,
+                track_posterior=True, track_exact_ELBO=True, save_freq=2, q_nograd_its=2)
+    elbo, nll_tr, nll_dev, err_tr, err_dev, q_app, q_true, lik, exact, basedir = out
+    assert np.all(np.isfinite(elbo)) and elbo[-1] > elbo[0]          # the ELBO estimate improves
+    assert err_tr[-1] < err_tr[0]
+    assert q_app.shape == (6, 4) and q_true.shape == (6, 4) and exact.shape == (6,)
+    assert np.allclose(q_app[0], q_app[1]) and not np.allclose(q_app[1], q_app[3])   # q frozen for 2 epochs
+    assert nll_dev[0] != 0 and nll_dev[1] == 0 and nll_dev[2] != 0   # dev pass every 2nd epoch
+    assert os.path.exists(os.path.join(basedir, "models", "theta_last.dat"))
+    net2 = quiet(DUN_VI, arq_uncert_fc_resnet(1, 1, 24, 3), depth_categorical_VI([0.25] * 4, cuda=False), 300,
+                 cuda=False, regression=True)
+    quiet(net2.load, os.path.join(basedir, "models", "theta_last.dat"))
+    assert net2.epoch >= 1
