@@ -94,13 +94,13 @@ def kernel_rooflines(net, B_local, reps):
     flops = 2.0 * B_local * W * W
     scratch = torch.empty_like(Z0)
     ms = timed(lambda: be.gemm(H0, w0, B_local, W, W, bias=b0, relu=True, colstats=True, out=scratch), reps)
-    out["gemm_fwd"] = dict(kernel="gemm_f32_kernel<A_KC=1,B_KC=1> (block forward: bias+ReLU+BN stats)",
+    out["gemm_fwd"] = dict(kernel="gemm_f32_dma_kernel<A_KC=1,B_KC=1> (block forward: bias+ReLU+BN stats)",
                            ms=ms, tflops=flops / ms / 1e9)
     ms = timed(lambda: be.gemm(Z0, w0, B_local, W, W, a_kcontig=True, b_kcontig=False, R=scratch, out=scratch), reps)
-    out["gemm_dx"] = dict(kernel="gemm_f32_kernel<A_KC=1,B_KC=0> (dX = dU W + g)", ms=ms, tflops=flops / ms / 1e9)
+    out["gemm_dx"] = dict(kernel="gemm_f32_dma_kernel<A_KC=1,B_KC=0> (dX = dU W + g)", ms=ms, tflops=flops / ms / 1e9)
     gw = model.stacked_grad["w"][0]
     ms = timed(lambda: be.gemm(Z0, H0, W, W, B_local, a_kcontig=False, b_kcontig=False, out=gw), reps)
-    out["gemm_dw"] = dict(kernel="gemm_f32_kernel<A_KC=0,B_KC=0> (dW = dU^T H)", ms=ms, tflops=flops / ms / 1e9)
+    out["gemm_dw"] = dict(kernel="gemm_f32_dma_kernel<A_KC=0,B_KC=0> (dW = dU^T H)", ms=ms, tflops=flops / ms / 1e9)
     # head over all D*B hidden rows (O=1): reads 4*D*B*W bytes once
     Hall = buf.H.view(D * B_local, W)
     ms = timed(lambda: be.head_forward(Hall, model.stacked["w_out"], model.stacked["b_out"]), reps)
@@ -108,20 +108,41 @@ def kernel_rooflines(net, B_local, reps):
     dact = torch.randn(D * B_local, 1, device=Hall.device)
     ms = timed(lambda: be.head_backward(Hall, model.stacked["w_out"], dact, need_dH=False), reps)
     out["head_bwd"] = dict(ms=ms, gbs=4.0 * D * B_local * W / ms / 1e6)
-    # fused ELBO pass on act_vec [D,B]: 8*D*B + 4*B algorithmic bytes
-    act = torch.randn(D, B_local, 1, device=Hall.device)
-    y = torch.randn(B_local, 1, device=Hall.device)
+    # fused ELBO pass (Gaussian likelihood + per-depth reduction + dact in one sweep) on act_vec [D,B]:
+    # 8*D*B + 4*B algorithmic bytes.  Timed as the bare C-ABI call on preallocated buffers.
+    from dun_amd import _lib as L
+    lib = L.lib()
     ls = net.f_neg_loglike.log_std.detach()
     ql = net.prob_model.q_logits.detach()
-    ms = timed(lambda: be.ll_pass(act, y, True, ls, ql, True, 1.0 / B_local, want_dact=True), reps)
-    out["elbo"] = dict(ms=ms, gbs=(8.0 * D * B_local + 4.0 * B_local) / ms / 1e6)
-    # the same kernel at a size that leaves the 256 MiB Infinity Cache (report a size sweep)
-    Bbig = 1 << 22
-    act = torch.randn(D, Bbig, 1, device=Hall.device)
-    y = torch.randn(Bbig, 1, device=Hall.device)
-    ms = timed(lambda: be.ll_pass(act, y, True, ls, ql, True, 1.0 / Bbig, want_dact=True), max(3, reps // 2))
-    out["elbo_large"] = dict(ms=ms, gbs=(8.0 * D * Bbig + 4.0 * Bbig) / ms / 1e6, B=Bbig)
+
+    def elbo_point(Bn, n):
+        act = torch.randn(D, Bn, device=Hall.device)
+        yv = torch.randn(Bn, device=Hall.device)
+        dact_o = torch.empty_like(act)
+        nparts = lib.dun_ll_num_partials(Bn, 1)
+        partials = torch.empty(D, nparts, device=Hall.device, dtype=torch.float64)
+        sp = L.stream_ptr(Hall.device)
+        ms_ = timed(lambda: L.check(lib.dun_ll_gauss(L.f32(act), L.f32(yv), L.f32(ls), L.f32(ql), 1, D, Bn, 1.0 / Bn,
+                                                     L.f32(dact_o), None, L.ptr(partials), sp)), n)
+        return dict(ms=ms_, gbs=(8.0 * D * Bn + 4.0 * Bn) / ms_ / 1e6, B=Bn)
+
+    out["elbo"] = elbo_point(B_local, 50)          # the workload's own act_vec: cache resident, launch bound
+    # the same kernel at sizes that leave the 256 MiB Infinity Cache (report a size sweep)
+    out["elbo_2e20"] = elbo_point(1 << 20, 20)
+    out["elbo_2e22"] = elbo_point(1 << 22, 10)
     return out
+
+
+def pmc_traffic(kernel, workload, world):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    2*FETCH_SIZE + WRITE_SIZE in bytes, gfx950 correction applied), valid for the single-GPU shapes it was taken on."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get(workload, {}).get(kernel)
+    except Exception:
+        return None
 
 
 def cpu_baseline(din, W, L, N_train, lr, momentum, wd, B_cpu):
@@ -226,7 +247,7 @@ def main():
         dom = kr["gemm_fwd"]
         result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                               "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_F32_PEAK_TF,
-                              "traffic": None, "ms_per_launch": dom["ms"],
+                              "traffic": pmc_traffic("gemm_fwd", args.workload, world), "ms_per_launch": dom["ms"],
                               "flop_per_launch": 2.0 * B_local * W * W}
         result["roofline_other_kernels"] = {
             k: ({"bound": "mfma", "achieved": v["tflops"], "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",

@@ -18,15 +18,22 @@ constexpr int GAUSS_PER_BLOCK = 4096;  // 256 threads x float4 x 4
 constexpr int ROWS_PER_BLOCK = 256;    // softmax rows per workgroup
 
 // weight of depth d: w[d], or softmax(w)[d] when the caller hands over logits (q = softmax(q_logits)).
-// Uniform addresses: the compiler turns these into scalar loads, every thread gets the same value.
-__device__ __forceinline__ float depth_weight(const float* __restrict__ w, int w_is_logits, int D, int d) {
+// Workgroup-cooperative: the max is a scalar loop (uniform loads, no transcendental), the D exponentials are
+// spread over the first wavefront (one expf per lane per 64 depths) and summed by a butterfly; `sh` is one
+// LDS float.  Contains a barrier: call from uniform control flow.  fp32 throughout, as F.softmax.
+__device__ __forceinline__ float depth_weight(const float* __restrict__ w, int w_is_logits, int D, int d, float* sh) {
     if (w == nullptr) return 0.f;
     if (!w_is_logits) return w[d];
     float mx = -INFINITY;
     for (int i = 0; i < D; ++i) mx = fmaxf(mx, w[i]);
-    float s = 0.f;
-    for (int i = 0; i < D; ++i) s += expf(w[i] - mx);
-    return expf(w[d] - mx) / s;
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < D; i += 64) s += expf(w[i] - mx);
+        s = wave_sum(s);
+        if (threadIdx.x == 0) *sh = s;
+    }
+    __syncthreads();
+    return expf(w[d] - mx) / *sh;
 }
 
 template <bool VEC>
@@ -37,8 +44,9 @@ __global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__
                                                        float* __restrict__ ll, double* __restrict__ partials,
                                                        int nparts) {
     __shared__ double red[4];
+    __shared__ float sh_w;
     const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
-    const float wd = depth_weight(w, w_is_logits, D, d);
+    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
     const float sigma = fmaxf(expf(log_std[0]), 1e-4f);
     const float inv_var = 1.f / (sigma * sigma);
     const float c0 = LOG_SQRT_2PI_F + logf(sigma);
@@ -94,7 +102,8 @@ __global__ __launch_bounds__(256) void ll_softmax_kernel(const float* __restrict
     const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     const int gl = tid % G, grp = tid / G;
     constexpr int NGROUPS = 256 / G;
-    const float wd = depth_weight(w, w_is_logits, D, d);
+    __shared__ float sh_w;
+    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
     const float coef = wd * inv_batch;
     const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
     float acc = 0.f;
