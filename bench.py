@@ -68,6 +68,48 @@ def build_net(din, W, L, N_train, lr, momentum, wd, cuda=True):
     return net
 
 
+IMAGE_WORKLOADS = {
+    # name: (channels, side, global batch, N_train)   ResNet-50 DUN, start_depth=1, end_depth=13 (D=12), 10 classes,
+    # SGD(lr 0.1, momentum 0.9, wd 1e-4): experiments/image/train_DUN.py:32,45-54 in the reference
+    "c4_mnist": (1, 28, 256, 60000),
+    "c5_cifar": (3, 32, 4096, 50000),
+}
+
+
+def build_image_net(channels, N_train):
+    from dun_amd.probability import depth_categorical_VI
+    from dun_amd.stochastic_img_resnets import resnet50
+    from dun_amd.training_wrappers import DUN_VI
+    torch.manual_seed(0)
+    model = resnet50(arch_uncert=True, start_depth=1, end_depth=13, num_classes=10, zero_init_residual=True,
+                     initial_conv="1x3", concat_pool=False, input_chanels=channels, p_drop=0)
+    D = model.n_layers
+    pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=True)
+    return quiet(DUN_VI, model, pm, N_train, lr=0.1, momentum=0.9, weight_decay=1e-4, cuda=True, regression=False)
+
+
+def image_head_rooflines(net, B_local, reps=20):
+    """The custom-kernel part of an image DUN step: batched head over [D*B, 2048] features + fused CE/ELBO."""
+    from dun_amd import kernels
+    be = kernels.backend()
+    D, K, C = net.model.n_layers, net.model.output_block.in_features, net.model.num_classes
+    dev = net.model.output_block.weight.device
+    feat = torch.randn(D * B_local, K, device=dev).relu()
+    w, b = net.model.output_block.weight.detach().contiguous(), net.model.output_block.bias.detach().contiguous()
+    out = {}
+    ms = timed(lambda: be.head_forward(feat, w, b), reps)
+    out["head_fwd"] = dict(ms=ms, gbs=4.0 * D * B_local * K / ms / 1e6)
+    dact = torch.randn(D * B_local, C, device=dev)
+    ms = timed(lambda: be.head_backward(feat, w, dact, need_dH=True), reps)
+    out["head_bwd_with_dfeat"] = dict(ms=ms, gbs=8.0 * D * B_local * K / ms / 1e6)
+    act = torch.randn(D, B_local, C, device=dev)
+    y = torch.randint(0, C, (B_local,), device=dev)
+    ql = net.prob_model.q_logits.detach()
+    ms = timed(lambda: be.ll_pass(act, y, False, None, ql, True, 1.0 / B_local, want_dact=True), reps)
+    out["elbo_softmax"] = dict(ms=ms, gbs=(8.0 * D * B_local * C + 8.0 * B_local) / ms / 1e6)
+    return out
+
+
 def timed(fn, n, stream_sync=True):
     """Average duration (ms) of n back-to-back calls, HIP events on the current stream."""
     fn()
@@ -172,14 +214,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3_wide", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3_wide", choices=sorted(WORKLOADS) + sorted(IMAGE_WORKLOADS))
     ap.add_argument("--no-sync-bn", action="store_true", help="per-replica BatchNorm statistics (not matched numerics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0)
     args = ap.parse_args()
 
-    din, W, L, B, N_train, lr, momentum, wd = WORKLOADS[args.workload]
+    image = args.workload in IMAGE_WORKLOADS
+    if image:
+        channels, side, B, N_train = IMAGE_WORKLOADS[args.workload]
+        lr, momentum, wd = 0.1, 0.9, 1e-4
+    else:
+        din, W, L, B, N_train, lr, momentum, wd = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -197,11 +244,17 @@ def main():
     assert B % world == 0
     B_local = B // world
 
-    net = build_net(din, W, L, N_train, lr, momentum, wd)
+    if image:
+        net = build_image_net(channels, N_train)
+        g = torch.Generator().manual_seed(rank)
+        x = torch.randn(B_local, channels, side, side, generator=g).cuda()
+        y = torch.randint(0, 10, (B_local,), generator=g).cuda()
+    else:
+        net = build_net(din, W, L, N_train, lr, momentum, wd)
+        x, y = shard_data(B_local, din, rank, torch.device("cuda", local_rank))
     if dist_on:
         from dun_amd.distributed import shard
         shard(net, sync_bn=not args.no_sync_bn)
-    x, y = shard_data(B_local, din, rank, torch.device("cuda", local_rank))
 
     def barrier():
         torch.cuda.synchronize()
@@ -226,6 +279,28 @@ def main():
         raise SystemExit("bench.py: non-finite training metrics %r" % (last,))
 
     result = None
+    if rank == 0 and image:
+        ms_step = dt / args.steps * 1e3
+        result = {
+            "metric": "DUN ELBO train samples/sec", "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: classification DUN_VI.fit, ResNet-50 DUN (start_depth 1, end_depth 13, D=12, "
+                                   "10 classes) on %dx%dx%d inputs, global batch %d (%d/GPU), conv trunk on MIOpen, "
+                                   "head + CE/ELBO on the HIP kernels" % (args.workload, channels, side, side, B, B_local),
+                       "parallelism": "dp%d batch-sharded, per-replica BatchNorm2d" % world,
+                       "train_metrics_last_step": list(last)}}
+        if not args.no_kernel_rooflines:
+            kr = image_head_rooflines(net, B_local)
+            result["roofline_other_kernels"] = {
+                k: {"bound": "hbm", "achieved": v["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": v["gbs"] / HBM_PEAK_GBS, "ms_per_launch": v["ms"]} for k, v in kr.items()}
+        print(json.dumps(result), flush=True)
+    if image:
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = B * args.steps / dt

@@ -66,6 +66,12 @@ class BaseNet(object):
         if self.scheduler is not None:
             self.scheduler.step()
 
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st.pop("_graph_state", None)  # captured hipGraphs do not pickle
+        st["_dist"] = None
+        return st
+
     def save(self, filename, best_err=None):
         cprint("c", "Writting %s\n" % filename)
         state = {"epoch": self.epoch, "lr": self.lr, "model": self.model, "prob_model": self.prob_model,
@@ -87,6 +93,7 @@ class BaseNet(object):
         self.f_neg_loglike = state["f_neg_loglike"]
         self.optimizer = state["optimizer"]
         self.scheduler = state["scheduler"]
+        self.__dict__.pop("_graph_state", None)
         print("  restoring epoch: %d, lr: %f" % (self.epoch, self.lr))
         if "best_err" in state:
             return self.epoch, state["best_err"]

@@ -279,3 +279,33 @@ def test_sharded_path_world1_matches_unsharded():
         assert np.allclose(net.eval(x, y), ref.eval(x, y), rtol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["c2_boston", "cls_fc", "mll_small"])
+def test_graphed_step_is_bit_identical_to_eager(name, monkeypatch):
+    """The whole-step hipGraph (captured on the 2nd call) must reproduce the eager launch sequence exactly, also
+    across an lr change (re-capture) and with eval/predict calls in between."""
+    c = Case(name)
+    x, y = c.t("x").cuda(), c.y().cuda()
+    monkeypatch.setenv("DUN_NO_GRAPH", "1")
+    eager = build_net(c)
+    want = [eager.fit(x, y) for _ in range(4)]
+    eager.optimizer.param_groups[0]["lr"] *= 0.1
+    want += [eager.fit(x, y) for _ in range(3)]
+    want_eval = eager.eval(x, y)
+    monkeypatch.delenv("DUN_NO_GRAPH")
+    net = build_net(c)
+    got = []
+    for i in range(4):
+        got.append(net.fit(x + 0 if i % 2 else x, y))      # fresh input tensors: the graph owns static copies
+        if i == 2:
+            net.predict(c.t("x_test"))                     # eager inference between replays
+    assert net._graph_state["graph"] is not None
+    net.optimizer.param_groups[0]["lr"] *= 0.1
+    got += [net.fit(x, y) for _ in range(3)]
+    assert np.array_equal(np.array(got), np.array(want), equal_nan=True), (got, want)
+    assert torch.equal(net.model.flat_params, eager.model.flat_params)
+    assert torch.equal(net.model.running_var, eager.model.running_var)
+    assert torch.equal(net.model.num_batches_tracked, eager.model.num_batches_tracked)
+    assert torch.equal(net.prob_model.current_posterior, eager.prob_model.current_posterior)
+    assert np.array_equal(np.array(net.eval(x, y)), np.array(want_eval), equal_nan=True)
