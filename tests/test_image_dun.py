@@ -5,6 +5,9 @@ the conv trunk on MIOpen."""
 import contextlib
 import io
 import json
+import os
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # keep MIOpen's per-shape search short on a cold GPU box
 
 import numpy as np
 import pytest
@@ -33,6 +36,7 @@ def build(c, cuda):
     net = quiet(DUN_VI, model, pm, meta["N"], lr=meta["lr"], momentum=meta["momentum"], weight_decay=meta["wd"],
                 cuda=cuda, regression=False)
     pm.q_logits.data.copy_(c.t("q_logits0"))
+    torch.backends.cudnn.benchmark = False  # (the wrapper turns MIOpen's benchmark search on, as the reference does)
     return net, meta
 
 
