@@ -8,6 +8,8 @@ Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the real referen
 ``/root/reference`` in the build container, runs it on seeded inputs and commits the inputs/outputs as
 ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function below against those vectors.
 (The reference itself ships no tests or golden vectors -- SURVEY.md F6.)
+The functions are device-agnostic plain torch: the full-size parity tests (tests/test_fullsize_gpu.py) evaluate them on
+device tensors (torch's own fp32/fp64 kernels) where the CPU would need minutes; it remains the checker there.
 
 Reference locations each function follows (paths relative to the reference repo):
   fc_forward ............ src/DUN/stochastic_fc_models.py:62-70, src/DUN/layers.py:33-53

@@ -1,0 +1,146 @@
+"""Full-size parity (BASELINE configs[2] geometry: width 2048, batch 65536): one train-mode forward + fused objective +
+backward of dun_amd against the oracle's functions evaluated on the same device tensors through torch's own fp32 /
+fp64 kernels (the oracle is device-agnostic plain torch; on the GPU it finishes in seconds at this size), plus the
+size-independent properties of the path: invariance of the per-depth sums under a permutation of the batch rows and
+additivity of the likelihood sums over batch shards.
+"""
+import contextlib
+import io
+
+import pytest
+import torch
+
+from oracle import dun_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DIN, W, N_TRAIN = 64, 2048, 1 << 20
+
+
+def build(L):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    import bench
+    with contextlib.redirect_stdout(io.StringIO()):
+        return bench.build_net(DIN, W, L, N_TRAIN, 1e-4, 0.5, 0.0)
+
+
+def data(B):
+    import bench
+    return bench.shard_data(B, DIN, 0, torch.device("cuda"))
+
+
+def ours(net, x, y):
+    net.model.train()
+    act = net.model.forward(x)
+    prior = net.model.get_w_prior_loglike(k=None)
+    out = net.prob_model.fused_objective(prior, act, y, net.f_neg_loglike, N_TRAIN)
+    net._backward(act, prior, out)
+    torch.cuda.synchronize()
+    return act.detach(), out
+
+
+def oracle_on_device(net, x, y, L, dt):
+    p = {k: net.model.stacked[k].detach().to(dt).clone().requires_grad_(True) for k in O.PARAM_KEYS}
+    p["running_mean"] = torch.zeros(L, W, device="cuda", dtype=dt)
+    p["running_var"] = torch.ones(L, W, device="cuda", dtype=dt)
+    p["num_batches_tracked"] = torch.zeros(L, dtype=torch.int64, device="cuda")
+    ql = net.prob_model.q_logits.detach().to(dt).clone().requires_grad_(True)
+    ls = net.f_neg_loglike.log_std.detach().to(dt).clone().requires_grad_(True)
+    D = L + 1
+    logprior = torch.full((D,), 1.0 / D, device="cuda", dtype=dt).log()
+    a = O.fc_forward(p, x.to(dt), train=True)
+    joint = O.joint_loglike(torch.zeros(D, device="cuda", dtype=dt), a, y.to(dt), True, N_TRAIN, ls)
+    elbo = (O.q_probs(ql) * joint).sum() - O.kl_q_prior(ql, logprior)
+    names = list(O.PARAM_KEYS) + ["q_logits", "log_std"]
+    g = torch.autograd.grad(-elbo / N_TRAIN, [p[k] for k in O.PARAM_KEYS] + [ql, ls])
+    return a.detach(), joint.detach(), elbo.detach(), dict(zip(names, g))
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def our_grads(net):
+    g = {k: net.model.stacked_grad[k] for k in O.PARAM_KEYS}
+    g["q_logits"] = net.prob_model.q_logits.grad
+    g["log_std"] = net.f_neg_loglike.log_std.grad
+    return g
+
+
+def test_full_batch_four_blocks_against_fp64_and_fp32_oracle():
+    L, B = 4, 65536
+    net = build(L)
+    x, y = data(B)
+    act, out = ours(net, x, y)
+    a64, j64, e64, g64 = oracle_on_device(net, x, y, L, torch.float64)
+    a32, j32, e32, g32 = oracle_on_device(net, x, y, L, torch.float32)
+    # north-star bar: 1e-5 relative on per-depth log-likelihood sums, ELBO (and the activations behind them)
+    assert rel(act, a64) < 1e-5
+    assert rel(out.joint, j64) < 1e-5 and rel(out.joint, j32) < 1e-5
+    assert rel(out.objective, e64) < 1e-5 and rel(out.objective, e32) < 1e-5
+    # gradients: ReLU sign coin-tosses near 0 move fp32 gradients by O(1/B); the budget is the fp32
+    # oracle's own distance from the fp64 evaluation, in the l2 norm over each tensor
+    g = our_grads(net)
+    for k in g:
+        mine, theirs = rel2(g[k], g64[k]), rel2(g32[k], g64[k])
+        assert mine <= 4.0 * theirs + 2e-5, (k, mine, theirs)
+
+
+def test_full_config_fifty_blocks_against_fp32_oracle():
+    L, B = 50, 65536
+    net = build(L)
+    x, y = data(B)
+    act, out = ours(net, x, y)
+    a32, j32, e32, g32 = oracle_on_device(net, x, y, L, torch.float32)
+    assert rel(act, a32) < 1e-5
+    assert rel(out.joint, j32) < 1e-5
+    assert rel(out.objective, e32) < 1e-5
+    g = our_grads(net)
+    assert rel(g["q_logits"], g32["q_logits"]) < 1e-5
+    assert rel(g["log_std"], g32["log_std"]) < 1e-5
+    assert rel(g["w_out"], g32["w_out"]) < 1e-4 and rel(g["b_out"], g32["b_out"]) < 1e-4
+    for k in ("w_in", "b_in", "w", "b", "gamma", "beta"):
+        # two fp32 evaluations of a 50-block ReLU/BN net: sign flips of near-zero pre-activations dominate
+        assert rel2(g[k], g32[k]) < 3e-3, (k, rel2(g[k], g32[k]))
+
+
+def test_batch_permutation_leaves_depth_sums_unchanged():
+    L, B = 6, 65536
+    net = build(L)
+    x, y = data(B)
+    _, out = ours(net, x, y)
+    j1, e1 = out.joint.clone(), out.objective.clone()
+    gw1 = net.model.stacked_grad["w"].clone()
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    net2 = build(L)
+    _, out2 = ours(net2, x[perm].contiguous(), y[perm].contiguous())
+    assert rel(out2.joint, j1) < 2e-6
+    assert rel(out2.objective, e1) < 2e-6
+    assert rel2(net2.model.stacked_grad["w"], gw1) < 1e-3
+
+
+def test_likelihood_sums_add_over_batch_shards():
+    """Sum_b loglike[d,b] over the full batch equals the sum of the shard sums (what the N-GPU path all-reduces)."""
+    from dun_amd import kernels
+    be = kernels.backend()
+    D, B = 51, 65536
+    g = torch.Generator(device="cuda").manual_seed(11)
+    act = torch.randn(D, B, 1, device="cuda", generator=g)
+    y = torch.randn(B, 1, device="cuda", generator=g)
+    ls = torch.tensor([-0.3], device="cuda")
+    ql = torch.randn(D, device="cuda", generator=g)
+    full = be.ll_pass(act, y, True, ls, ql, True, 1.0 / B, want_dact=False)[0]
+    parts = None
+    for r in range(8):
+        sl = slice(r * B // 8, (r + 1) * B // 8)
+        s = be.ll_pass(act[:, sl].contiguous(), y[sl].contiguous(), True, ls, ql, True, 1.0 / B, want_dact=False)[0]
+        parts = s if parts is None else parts + s
+    # fp32 only inside a thread's <= 16 elements, fp64 from there on: regrouping moves the sums by ~1e-8 relative
+    assert rel(parts, full) < 1e-6
