@@ -4,14 +4,14 @@
 // features of every exit (image DUNs).  Here the D*B rows are one HBM stream: a wavefront takes a row,
 // lanes take 16-byte column chunks, O accumulators per lane, one butterfly reduction per output.  With O
 // small (1 for regression, 10 for MNIST/CIFAR) this is bandwidth bound: 4*K bytes per row read once.
-// Backward streams the same rows once more: thread-owned column chunks accumulate dw over 1024-row slabs
+// Backward streams the same rows once more: thread-owned column chunks accumulate dw over slabs of up to 1024 rows
 // (fixed-order LDS combine, then an fp64 reduction over slabs: reproducible), db rides along, and the
 // optional dH = dact w is written in the same pass for callers that need it (the image trunk's autograd).
 #include "common.h"
 
 namespace dun {
 
-constexpr int HSLAB = 1024;  // rows per dw partial
+constexpr int HSLAB_MAX = 1024;  // rows per dw partial (upper bound; small inputs take shorter slabs)
 constexpr int HCX = 64, HRY = 4;
 
 template <int OC, bool VEC>
@@ -54,14 +54,73 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
-// One workgroup: 64 column-chunks x 4 row lanes over a slab of HSLAB rows.  o0: first output of this launch.
+// O > 4 (10-class image DUNs): the kernel above issues O weight loads per 16 bytes of H and is bound by load issue,
+// not by HBM.  Here a wavefront takes R consecutive rows, so a weight chunk is loaded once per R rows, and the R*O
+// lane-partials are reduced together by a halving butterfly: at the xor-32/16/8/4 steps a lane keeps one value of
+// each pair and ships the other, so R*O values cost ~R*O shuffles instead of 6*R*O.  After four halvings lane l holds
+// value 16*i + 8*b2 + 4*b3 + 2*b4 + b5 (bk = bit k of l) in slot i; value index = r*O + j is the output offset.
+template <int O, int R>
+__global__ __launch_bounds__(256) void head_fwd_rows_kernel(const float* __restrict__ H, const float* __restrict__ w,
+                                                            const float* __restrict__ b, int rows, int K,
+                                                            float* __restrict__ act) {
+    static_assert((R * O) % 16 == 0, "four halving steps need R*O divisible by 16");
+    constexpr int NV = R * O;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int row0 = wave * R; row0 < rows; row0 += nwaves * R) {
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            f32x4 hv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                hv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row0 + r < rows) hv[r] = *reinterpret_cast<const f32x4*>(H + (size_t)(row0 + r) * K + k);
+            }
+#pragma unroll
+            for (int j = 0; j < O; ++j) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)j * K + k);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    v[r * O + j] += (hv[r][0] * wv[0] + hv[r][1] * wv[1]) + (hv[r][2] * wv[2] + hv[r][3] * wv[3]);
+            }
+        }
+#define DUN_HALVE(N, OFF)                                            \
+    _Pragma("unroll") for (int i = 0; i < (N) / 2; ++i) {            \
+        const bool up = (lane & (OFF)) != 0;                         \
+        const float keep = up ? v[2 * i + 1] : v[2 * i];             \
+        const float send = up ? v[2 * i] : v[2 * i + 1];             \
+        v[i] = keep + __shfl_xor(send, (OFF), 64);                   \
+    }
+        DUN_HALVE(NV, 32)
+        DUN_HALVE(NV / 2, 16)
+        DUN_HALVE(NV / 4, 8)
+        DUN_HALVE(NV / 8, 4)
+#undef DUN_HALVE
+        const int sub = ((lane >> 2) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+#pragma unroll
+        for (int i = 0; i < NV / 16; ++i) {
+            float t = v[i];
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 1, 64);
+            const int idx = 16 * i + sub;  // = r * O + j
+            if ((lane & 3) == 0 && row0 + idx / O < rows) act[(size_t)row0 * O + idx] = t + b[idx % O];
+        }
+    }
+}
+
+// One workgroup: 64 column-chunks x 4 row lanes over a slab of slab_rows rows.  o0: first output of this launch.
 template <int OC, int VW>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
                                                        const float* __restrict__ dact, int rows, int K, int O, int o0,
                                                        float* __restrict__ part_dw, float* __restrict__ part_db,
-                                                       float* __restrict__ dH, int nslab) {
+                                                       float* __restrict__ dH, int slab_rows) {
     __shared__ float red[HRY][HCX * VW];
-    const int tx = threadIdx.x & (HCX - 1), ty = threadIdx.x >> 6;
+    // ty is the wavefront index; with several outputs, telling the compiler so turns the O per-row dact loads into
+    // scalar loads (one output: the single vector load is cheaper than the scalar-load latency)
+    const int tx = threadIdx.x & (HCX - 1);
+    const int ty = OC > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     const int c = (blockIdx.x * HCX + tx) * VW;
     const int slab = blockIdx.y;
     const bool live = c < K;
@@ -75,9 +134,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             wv[j][e] = (dH && live && o0 + j < O) ? w[(size_t)(o0 + j) * K + c + e] : 0.f;
         }
     }
-    const int r1 = min(rows, (slab + 1) * HSLAB);
+    const int r1 = min(rows, (slab + 1) * slab_rows);
     if (live) {
-        for (int r = slab * HSLAB + ty; r < r1; r += HRY) {
+        for (int r = slab * slab_rows + ty; r < r1; r += HRY) {
             float hv[VW];
             if (VW == 4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(H + (size_t)r * K + c);
@@ -159,6 +218,7 @@ static int pick_oc(int O) {
     if (O <= 2) return 2;
     if (O <= 4) return 4;
     if (O <= 8) return 8;
+    if (O <= 10) return 10;  // the 10-class heads of the image DUNs
     return 16;
 }
 
@@ -166,6 +226,13 @@ int head_forward(const float* H, const float* w, const float* b, int rows, int K
     DUN_REQUIRE(H && w && b && act, "dun_head_forward: null pointer");
     DUN_REQUIRE(rows > 0 && K > 0 && O > 0, "dun_head_forward: empty input rows=%d K=%d O=%d", rows, K, O);
     const bool vec = K % 4 == 0 && aligned16(H) && aligned16(w);
+    if (vec && O == 10) {  // MNIST / CIFAR-10 heads of the image DUNs
+        int g = ceil_div(rows, 4 * 8);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL((head_fwd_rows_kernel<10, 8>), dim3(g), dim3(256), 0, s, H, w, b, rows, K, act);
+        DUN_LAUNCH_CHECK();
+        return DUN_OK;
+    }
     int grid = ceil_div(rows, 4);
     if (grid > 4096) grid = 4096;
 #define HF(OC)                                                                                              \
@@ -178,6 +245,7 @@ int head_forward(const float* H, const float* w, const float* b, int rows, int K
         case 2: HF(2); break;
         case 4: HF(4); break;
         case 8: HF(8); break;
+        case 10: HF(10); break;
         default: HF(16); break;
     }
 #undef HF
@@ -185,8 +253,19 @@ int head_forward(const float* H, const float* w, const float* b, int rows, int K
     return DUN_OK;
 }
 
+// rows per slab: about 1024 workgroups over the (column block, slab) grid, 64..HSLAB_MAX rows each
+static int head_slab_rows(int rows, int K) {
+    const int colblocks = ceil_div(K, HCX * 4);
+    const int want = 1024 / colblocks > 0 ? 1024 / colblocks : 1;
+    int sr = ceil_div(rows, want);
+    sr = (sr + 7) & ~7;
+    if (sr < 64) sr = 64;
+    if (sr > HSLAB_MAX) sr = HSLAB_MAX;
+    return sr;
+}
+
 size_t head_backward_ws(int rows, int K, int O) {
-    const size_t nslab = (size_t)ceil_div(rows, HSLAB);
+    const size_t nslab = (size_t)ceil_div(rows, head_slab_rows(rows, K));
     return nslab * (size_t)O * (size_t)K + nslab * (size_t)O + 64;
 }
 
@@ -195,7 +274,8 @@ int head_backward(const float* H, const float* w, const float* dact, int rows, i
     DUN_REQUIRE(H && w && dact && dw && db && ws, "dun_head_backward: null pointer");
     DUN_REQUIRE(rows > 0 && K > 0 && O > 0, "dun_head_backward: empty input rows=%d K=%d O=%d", rows, K, O);
     DUN_REQUIRE(ws_floats >= head_backward_ws(rows, K, O), "dun_head_backward: workspace too small");
-    const int nslab = ceil_div(rows, HSLAB);
+    const int slab_rows = head_slab_rows(rows, K);
+    const int nslab = ceil_div(rows, slab_rows);
     float* part_dw = ws;
     float* part_db = ws + (size_t)nslab * O * K;
     const bool vec = K % 4 == 0 && aligned16(H) && aligned16(w) && (!dH || aligned16(dH));
@@ -204,15 +284,16 @@ int head_backward(const float* H, const float* w, const float* dact, int rows, i
 #define HB(OC)                                                                                                   \
     do {                                                                                                         \
         if (vec) hipLaunchKernelGGL((head_bwd_kernel<OC, 4>), dim3(ceil_div(K, HCX * 4), nslab), dim3(256), 0, s, H, w, \
-                                    dact, rows, K, O, o0, part_dw, part_db, dH, nslab);                          \
+                                    dact, rows, K, O, o0, part_dw, part_db, dH, slab_rows);                      \
         else hipLaunchKernelGGL((head_bwd_kernel<OC, 1>), dim3(ceil_div(K, HCX), nslab), dim3(256), 0, s, H, w, dact,   \
-                                rows, K, O, o0, part_dw, part_db, dH, nslab);                                    \
+                                rows, K, O, o0, part_dw, part_db, dH, slab_rows);                                \
     } while (0)
         switch (oc) {
             case 1: HB(1); break;
             case 2: HB(2); break;
             case 4: HB(4); break;
             case 8: HB(8); break;
+            case 10: HB(10); break;
             default: HB(16); break;
         }
 #undef HB

@@ -199,7 +199,8 @@ def test_head_golden(be):
     assert rel_err(dH.cpu().view(D, B, K), h["g_feat"]) < 2e-5
 
 
-@pytest.mark.parametrize("rows,K,O", [(5000, 2048, 1), (3000, 100, 1), (700, 50, 2), (1500, 512, 10), (300, 64, 20)])
+@pytest.mark.parametrize("rows,K,O", [(5000, 2048, 1), (3000, 100, 1), (700, 50, 2), (1500, 512, 10), (300, 64, 20),
+                                                  (4099, 2048, 10), (37, 256, 10), (3, 64, 10), (2051, 100, 9)])
 def test_head_shapes(be, rows, K, O):
     g = torch.Generator().manual_seed(rows + K + O)
     H, w, b = torch.randn(rows, K, generator=g), torch.randn(O, K, generator=g), torch.randn(O, generator=g)
