@@ -17,7 +17,7 @@ RES_OBJECTIVE, RES_E_LOGLIKE, RES_KL, RES_LOG_MARG, RES_DLOG_STD, RES_HEADER = 0
 
 EXPORTS = [
     "dun_abi_version", "dun_last_error", "dun_ll_num_partials", "dun_ll_gauss", "dun_ll_softmax", "dun_ll_reduce",
-    "dun_depth_finalize", "dun_predict_gauss", "dun_predict_softmax", "dun_predict_num_partials", "dun_gemm_f32",
+    "dun_depth_finalize", "dun_predict_gauss", "dun_predict_softmax", "dun_predict_num_partials", "dun_gemm_f32", "dun_gemm_colstat_tiles",
     "dun_fc_workspace_floats", "dun_fc_forward", "dun_fc_backward", "dun_fc_input_layer", "dun_fc_block_linear",
     "dun_fc_block_norm", "dun_fc_head", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply",
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
@@ -72,6 +72,7 @@ def _declare(lib):
         "dun_predict_gauss": (i, [vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp]),
         "dun_predict_softmax": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp]),
         "dun_gemm_f32": (i, [C.POINTER(GemmDesc), vp]),
+        "dun_gemm_colstat_tiles": (i, [i, i]),
         "dun_fc_workspace_floats": (sz, [i, i, i, i, i]),
         "dun_fc_forward": (i, [C.POINTER(FcCtx), vp]),
         "dun_fc_backward": (i, [C.POINTER(FcCtx), vp]),

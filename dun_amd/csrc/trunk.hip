@@ -16,6 +16,7 @@
 namespace dun {
 
 int gemm_f32(const dun_gemm_desc* d, hipStream_t s);
+int gemm_colstat_tiles(int M, int N);
 int head_forward(const float* H, const float* w, const float* b, int rows, int K, int O, float* act, hipStream_t s);
 int head_backward(const float* H, const float* w, const float* dact, int rows, int K, int O, float* dw, float* db,
                   float* dH, float* ws, size_t ws_floats, hipStream_t s);
@@ -345,7 +346,7 @@ static int input_layer(const dun_fc_ctx* c, hipStream_t s) {
 }
 
 static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s) {
-    const int W = c->W, P = num_slabs(c->B);
+    const int W = c->W, P = gemm_colstat_tiles(c->B, W);  // the GEMM's own row tiling (128, or 64 on small problems)
     dun_gemm_desc g;
     memset(&g, 0, sizeof(g));
     g.A = Hd(c, i); g.lda = W; g.a_kcontig = 1;
@@ -516,7 +517,7 @@ using namespace dun;
 
 extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
     (void)din;
-    const size_t P = (size_t)num_slabs(B);
+    const size_t P = (size_t)ceil_div(B, 64);  // upper bound of the GEMM's row tiles (and of num_slabs(B))
     const size_t cols = 4 * P * (size_t)W;  // fp64 [2][P][W] forward statistics partials
     const size_t hb = head_backward_ws((L + 1) * B, W, O);
     return (cols > hb ? cols : hb) + 64;

@@ -229,7 +229,7 @@ class HipBackend(object):
             d.U, d.V, d.O, d.ldv = L.f32(U), L.f32(V), U.shape[1], V.shape[1]
         stats = None
         if colstats:
-            stats = torch.empty(2, (M + 127) // 128, N, device=dev, dtype=torch.float64)
+            stats = torch.empty(2, L.lib().dun_gemm_colstat_tiles(M, N), N, device=dev, dtype=torch.float64)
             d.colstats = L.ptr(stats)
         L.check(L.lib().dun_gemm_f32(C.byref(d), L.stream_ptr(dev)), "dun_gemm_f32")
         return (Cm, stats) if colstats else Cm

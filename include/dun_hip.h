@@ -118,9 +118,12 @@ typedef struct dun_gemm_desc {
     const float* U;    /* rank-O update: C += U[m*O + o] * V[o*ldv + n]; NULL for none */
     const float* V;
     int O, ldv;
-    double* colstats;  /* NULL, or fp64 [2][ceil(M/128)][N]: per 128-row tile column sums of C and C^2 */
+    double* colstats;  /* NULL, or fp64 [2][T][N], T = dun_gemm_colstat_tiles(M, N): per row-tile column sums of C, C^2 */
 } dun_gemm_desc;
 int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream);
+/* Row tiles the kernel uses for an M x N problem (128-row tiles; 64-row tiles when the problem is too small to fill
+ * the chip with 128x128 tiles).  No reference counterpart: sizing helper for `colstats`. */
+int dun_gemm_colstat_tiles(int M, int N);
 
 /* ------------------------------------------------------------------------------------------------------
  * Residual-MLP trunk ("forward_get_acts"): arq_uncert_fc_resnet.forward / arq_uncert_fc_MLP

@@ -31,8 +31,11 @@ def dev(t):
 # ------------------------------------------------------------------------------------------------------
 GEMM_SHAPES = [(128, 128, 32), (256, 384, 160), (300, 100, 100), (512, 100, 13), (300, 100, 1), (1, 1, 1),
                (129, 257, 67), (1024, 256, 256), (100, 13, 512), (64, 2048, 96), (5, 3, 1000),
-               # tile-aligned problems take the LDS-DMA kernel (M%128 == N%128 == K%32 == 0)
-               (256, 256, 2048), (2048, 128, 64), (128, 2048, 4096)]
+               (256, 256, 2048), (2048, 128, 64), (128, 2048, 4096),
+               # everything above is under 128 tiles of 128x128 and takes the 64x64-tile kernel; from 128 tiles on:
+               # tile-aligned problems take the LDS-DMA kernel (M%128 == N%128 == K%32 == 0), ragged ones the
+               # register-staged 128x128 kernel
+               (2048, 1024, 64), (1024, 2048, 96), (4096, 512, 2048), (2050, 1030, 70), (1153, 1800, 33)]
 
 
 @pytest.mark.parametrize("a_kc", [True, False])
@@ -50,7 +53,8 @@ def test_gemm_layouts(be, M, N, K, a_kc, b_kc):
     assert (C.double() - ref).abs().max().item() <= 4e-7 * bound + 1e-30
 
 
-@pytest.mark.parametrize("M,N,K,O", [(256, 128, 64, 1), (300, 100, 100, 1), (130, 200, 36, 3), (512, 256, 256, 10)])
+@pytest.mark.parametrize("M,N,K,O", [(256, 128, 64, 1), (300, 100, 100, 1), (130, 200, 36, 3), (512, 256, 256, 10),
+                                     (2048, 1024, 64, 2), (2050, 1030, 70, 1)])
 def test_gemm_epilogues(be, M, N, K, O):
     g = torch.Generator().manual_seed(5)
     A, Bw = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
