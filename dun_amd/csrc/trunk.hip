@@ -22,7 +22,9 @@ int head_backward(const float* H, const float* w, const float* dact, int rows, i
                   float* dH, float* ws, size_t ws_floats, hipStream_t s);
 size_t head_backward_ws(int rows, int K, int O);
 
-constexpr int SLAB = 128;  // rows per column-reduction partial (same as the GEMM tile height)
+// rows per column-reduction partial: 128, or 32 for small batches (four times the workgroups, a quarter of the serial
+// row loop: the UCI-sized nets are latency bound)
+static inline int slab_rows_for(int B) { return B >= 8192 ? 128 : 32; }
 constexpr int CX = 64;     // threads across columns in the elementwise / column kernels
 constexpr int RY = 4;      // row lanes per workgroup
 
@@ -131,7 +133,7 @@ template <int VW>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ Z,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int B, int W, int P,
-                                                            float* __restrict__ partials) {
+                                                            int SLAB, float* __restrict__ partials) {
     typedef Vec<VW> V;
     __shared__ float red[2][RY][CX * VW];
     const int tx = threadIdx.x & (CX - 1), ty = threadIdx.x >> 6;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, double count, int B,
-                                                           int W, float* __restrict__ dU,
+                                                           int W, int SLAB, float* __restrict__ dU,
                                                            float* __restrict__ partials) {
     typedef Vec<VW> V;
     __shared__ float red[RY][CX * VW];
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // per-slab column sums of X [B,W] -> partials [P][W]
 template <int VW>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int B, int W,
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int B, int W, int SLAB,
                                                      float* __restrict__ partials) {
     typedef Vec<VW> V;
     __shared__ float red[RY][CX * VW];
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 // ---------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------
-static inline int num_slabs(int B) { return ceil_div(B, SLAB); }
+static inline int num_slabs(int B) { return ceil_div(B, slab_rows_for(B)); }
 static inline bool vec4_ok(int W, const void* a, const void* b = nullptr, const void* c = nullptr) {
     return W % 4 == 0 && aligned16(a) && (!b || aligned16(b)) && (!c || aligned16(c));
 }
@@ -441,10 +443,10 @@ static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
     const float* rstd = c->bn_rstd + (size_t)i * W;
     if (vec4_ok(W, c->G, Z))
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean, rstd, B,
-                           W, P, c->ws);
+                           W, P, slab_rows_for(B), c->ws);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, Z, mean, rstd, B, W,
-                           P, c->ws);
+                           P, slab_rows_for(B), c->ws);
     DUN_LAUNCH_CHECK();
     // local sums are this rank's dbeta / dgamma; the fp64 copy is what a sharded job all-reduces
     hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, c->ws, P, W, c->bn_sums,
@@ -461,10 +463,10 @@ static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipS
     const float* gamma = c->p.gamma + (size_t)i * W;
     if (vec4_ok(W, c->G, Z, c->dU))
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean, rstd,
-                           gamma, c->bn_sums, global_batch, B, W, c->dU, c->ws);
+                           gamma, c->bn_sums, global_batch, B, W, slab_rows_for(B), c->dU, c->ws);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, Z, mean, rstd, gamma,
-                           c->bn_sums, global_batch, B, W, c->dU, c->ws);
+                           c->bn_sums, global_batch, B, W, slab_rows_for(B), c->dU, c->ws);
     DUN_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W,
                        (double*)nullptr, c->g.b + (size_t)i * W, (float*)nullptr);
@@ -501,9 +503,9 @@ static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
     int rc = gemm_f32(&g, s);
     if (rc) return rc;
     if (vec4_ok(W, c->G))
-        hipLaunchKernelGGL(colsum_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, B, W, c->ws);
+        hipLaunchKernelGGL(colsum_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, B, W, slab_rows_for(B), c->ws);
     else
-        hipLaunchKernelGGL(colsum_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, B, W, c->ws);
+        hipLaunchKernelGGL(colsum_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, B, W, slab_rows_for(B), c->ws);
     DUN_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W,
                        (double*)nullptr, c->g.b_in, (float*)nullptr);
