@@ -147,7 +147,8 @@ def test_elbo_softmax_edges(be, C):
     assert abs(m[0].item() - nll_ref) < 1e-5 * abs(nll_ref) and m[1].item() == err_ref
 
 
-@pytest.mark.parametrize("D,B", [(51, 65536), (11, 512), (3, 4099), (7, 1)])
+# B >= 2^21 takes the depth-walking kernel: ragged last chunk, and D > 64 (more than one depth group per chunk)
+@pytest.mark.parametrize("D,B", [(51, 65536), (11, 512), (3, 4099), (7, 1), (5, (1 << 21) + 1028), (66, 1 << 21)])
 def test_elbo_gauss_sizes(be, D, B):
     g = torch.Generator().manual_seed(D * 1000 + B)
     act = torch.randn(D, B, 1, generator=g)
@@ -161,7 +162,11 @@ def test_elbo_gauss_sizes(be, D, B):
     cf = O.elbo_grads_closed_form(act.double(), y.double(), True, N, O.q_probs(ql.double()), log_std=ls.double(),
                                   q_logits=ql.double(), logprior=logprior, prior_loglikes=torch.zeros(D).double())
     assert rel_err(dact.view(D, B, 1), cf["dact"]) < 1e-5
-    assert rel_err(res[8 + 2 * D:8 + 3 * D], cf["dq_logits"]) < 1e-4
+    # dq_d = -q_d (joint_d - sum q joint)/N (+ KL term): a difference of O(q joint / N) terms, so the fp32 softmax(q)
+    # the reference also uses contributes eps32 * max|q joint|/N absolute error whatever the size of the result
+    dq, dq_ref = res[8 + 2 * D:8 + 3 * D].double(), cf["dq_logits"]
+    atol = 1e-4 * float(dq_ref.abs().max()) + 4e-7 * float((O.q_probs(ql.double()) * joint).abs().max()) / N
+    assert float((dq - dq_ref).abs().max()) < atol
     assert abs(float(res[4]) - float(cf["dlog_std"])) < 1e-5 * abs(float(cf["dlog_std"])) + 1e-9
 
 
