@@ -147,6 +147,27 @@ def test_elbo_softmax_edges(be, C):
     assert abs(m[0].item() - nll_ref) < 1e-5 * abs(nll_ref) and m[1].item() == err_ref
 
 
+# thread-per-row kernel (C <= 10 / 16 / 32, B*C % 4 == 0), its ragged last chunk, and the lane-group fallbacks
+# (B*C % 4 != 0, C > 32)
+@pytest.mark.parametrize("D,B,C", [(12, 4096, 10), (3, 1000, 10), (4, 258, 2), (5, 777, 10), (2, 300, 12), (3, 516, 17),
+                                    (2, 64, 32), (2, 300, 33), (12, 70000, 10), (1, 1, 10), (2, 3, 4)])
+def test_elbo_softmax_sizes(be, D, B, C):
+    g = torch.Generator().manual_seed(D * 100003 + B * 7 + C)
+    act = 3.0 * torch.randn(D, B, C, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    ql, N = 0.3 * torch.randn(D, generator=g), float(60000)
+    res, dact, ll, _ = _run_vi(be, act, y, False, ql, None, N)
+    logprior = torch.full((D,), 1.0 / D).log().double()
+    z = torch.zeros(D).double()
+    joint = O.joint_loglike(z, act.double(), y, False, N)
+    elbo = O.elbo(z, act.double(), y, False, N, ql.double(), logprior)
+    assert rel_err(res[8:8 + D], joint) < 1e-5 and rel_err(res[0], elbo) < 1e-5
+    assert rel_err(ll, O.loglike_per_act(act.double(), y, False)) < 1e-5
+    cf = O.elbo_grads_closed_form(act.double(), y, False, N, O.q_probs(ql.double()), q_logits=ql.double(),
+                                  logprior=logprior, prior_loglikes=z)
+    assert rel_err(dact, cf["dact"]) < 1e-5
+
+
 # B >= 2^21 takes the depth-walking kernel: ragged last chunk, and D > 64 (more than one depth group per chunk)
 @pytest.mark.parametrize("D,B", [(51, 65536), (11, 512), (3, 4099), (7, 1), (5, (1 << 21) + 1028), (66, 1 << 21)])
 def test_elbo_gauss_sizes(be, D, B):
