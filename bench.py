@@ -111,11 +111,24 @@ def image_head_rooflines(net, B_local, reps=20):
     dact = torch.randn(D * B_local, C, device=dev)
     ms = timed(lambda: be.head_backward(feat, w, dact, need_dH=True), reps)
     out["head_bwd_with_dfeat"] = dict(ms=ms, gbs=8.0 * D * B_local * K / ms / 1e6)
-    act = torch.randn(D, B_local, C, device=dev)
-    y = torch.randint(0, C, (B_local,), device=dev)
     ql = net.prob_model.q_logits.detach()
-    ms = timed(lambda: be.ll_pass(act, y, False, None, ql, True, 1.0 / B_local, want_dact=True), reps)
-    out["elbo_softmax"] = dict(ms=ms, gbs=(8.0 * D * B_local * C + 8.0 * B_local) / ms / 1e6)
+    from dun_amd import _lib as L
+    lib = L.lib()
+
+    def elbo_point(Bn, n):
+        """fused CE + per-depth sums + dact in one sweep, bare C-ABI call on preallocated buffers: 8*D*B*C + 8*B bytes"""
+        act = torch.randn(D, Bn, C, device=dev)
+        y = torch.randint(0, C, (Bn,), device=dev)
+        dact_o = torch.empty_like(act)
+        nparts = lib.dun_ll_num_partials(Bn, C)
+        partials = torch.empty(D, nparts, device=dev, dtype=torch.float64)
+        sp = L.stream_ptr(dev)
+        ms_ = timed(lambda: L.check(lib.dun_ll_softmax(L.f32(act), L.ptr(y), L.f32(ql), 1, D, Bn, C, 1.0 / Bn,
+                                                       L.f32(dact_o), None, L.ptr(partials), sp)), n)
+        return dict(ms=ms_, gbs=(8.0 * D * Bn * C + 8.0 * Bn) / ms_ / 1e6, B=Bn)
+
+    out["elbo_softmax"] = elbo_point(B_local, 50)      # the workload's own size: cache resident, latency bound
+    out["elbo_softmax_2e20"] = elbo_point(1 << 20, 10)  # HBM-resident size of the same kernel
     return out
 
 
