@@ -1,0 +1,33 @@
+"""Per-rank cost of the N-GPU sharded step, rehearsed on one GPU: the staged (BN-exchange) path at the local batch
+B/N of the c3_wide workload with a world-size-1 RCCL group (collectives are no-ops; kernels + host staging are real)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+import torch, torch.distributed as dist
+import bench
+from dun_amd.distributed import shard
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+din, W, L, B, N_train, lr, mom, wd = bench.WORKLOADS["c3_wide"]
+for N in (8, 4, 2, 1):
+    Bl = B // N
+    for sharded in (False, True):
+        net = bench.build_net(din, W, L, N_train, lr, mom, wd)
+        if sharded:
+            shard(net, sync_bn=True)
+        x, y = bench.shard_data(Bl, din, 0, torch.device("cuda"))
+        for _ in range(2):
+            net.fit(x, y)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            net.fit(x, y)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        net.fit(x, y)
+        host = time.perf_counter() - t0   # time until fit returns (includes the metrics D2H sync)
+        print("N=%d local batch %6d %-9s %.2f ms/step  (ideal-scaling throughput %.0f samples/s)" %
+              (N, Bl, "staged" if sharded else "fused", dt * 1e3, B / dt), flush=True)
+        del net
+        torch.cuda.empty_cache()
+dist.destroy_process_group()
