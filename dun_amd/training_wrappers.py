@@ -263,19 +263,25 @@ class DUN(BaseNet):
         with torch.no_grad():
             prior_loglikes = self.model.get_w_prior_loglike(k=None)
             N_train = len(trainloader.dataset)
-            assert N_train == self.N_train
+            world = 1 if self._dist is None else self._dist.world
+            # sharded: every rank's loader yields its rows of each global batch (the dataset it wraps is this rank's
+            # 1/world of the data, or the whole set behind a DistributedSampler); the objective of a batch is already
+            # the all-reduced, global-batch one
+            assert N_train == self.N_train or N_train * world == self.N_train
+            N_train = self.N_train
             cum = None
             for x, y in trainloader:
                 x, y = self._prepare(x, y)
                 act_vec = self.model.forward(x)
+                gb = x.shape[0] * world
                 if vi:
                     out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, N_train,
                                                           want_grad=False)
-                    term = (x.shape[0] / N_train) * out.objective.double()
+                    term = (gb / N_train) * out.objective.double()
                 else:
                     out = depth_categorical.fused_objective(self.prob_model, prior_loglikes, act_vec, y,
                                                             self.f_neg_loglike, N_train, want_grad=False)
-                    term = (x.shape[0] / N_train) * out.joint.double()
+                    term = (gb / N_train) * out.joint.double()
                 cum = term if cum is None else cum + term
             return cum
 

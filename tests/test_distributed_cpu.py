@@ -41,6 +41,24 @@ def _state(net):
     return out
 
 
+class _Loader(list):
+    """Two batches of a tensor dataset, with the `.dataset` the sweeps ask the length of."""
+    def __init__(self, x, y, n_dataset):
+        h = x.shape[0] // 2
+        super(_Loader, self).__init__([(x[:h], y[:h]), (x[h:2 * h], y[h:2 * h])])
+        self.dataset = range(n_dataset)
+
+
+def _sweeps(net, x, y, n_dataset):
+    """get_exact_d_posterior (+ get_exact_ELBO for VI) over a two-batch loader, eval-mode BatchNorm."""
+    loader = _Loader(x, y, n_dataset)
+    post, log_marg = net.get_exact_d_posterior(loader, train_bn=False, logposterior=True)
+    out = [post.cpu().numpy(), log_marg]
+    if hasattr(net, "get_exact_ELBO"):
+        out.append(net.get_exact_ELBO(loader, train_bn=False))
+    return out
+
+
 def _worker(rank, world, port, name, sync_bn, steps, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -60,7 +78,8 @@ def _worker(rank, world, port, name, sync_bn, steps, ret):
         rets = [net.fit(xs, ys) for _ in range(steps)]
         ev = net.eval(xs, ys)
         st = _state(net)
-        ret[rank] = (rets, ev, {k: v.numpy() for k, v in st.items()})
+        sweep = _sweeps(net, xs, ys, c.cfg["N"] // world)
+        ret[rank] = (rets, ev, {k: v.numpy() for k, v in st.items()}, sweep)
     finally:
         dist.destroy_process_group()
 
@@ -79,19 +98,30 @@ def _single(name, steps=2):
     x, y = c.t("x"), c.y()
     rets = [net.fit(x, y) for _ in range(steps)]
     ev = net.eval(x, y)
+    # the same two global batches the two ranks see half of each: rows [0,h/2)+[B/2,B/2+h/2), ...
+    B = x.shape[0]
+    h = B // 4
+    idx = torch.cat([torch.arange(0, h), torch.arange(B // 2, B // 2 + h), torch.arange(h, 2 * h),
+                     torch.arange(B // 2 + h, B // 2 + 2 * h)])
+    sweep = _sweeps(net, x[idx], y[idx], c.cfg["N"])
     from dun_amd import kernels
     kernels.set_backend(None)
-    return rets, ev, {k: v.numpy() for k, v in _state(net).items()}
+    return rets, ev, {k: v.numpy() for k, v in _state(net).items()}, sweep
 
 
 @pytest.mark.parametrize("name", ["c3_reduced", "cls_fc", "mll_small"])
 def test_two_ranks_match_single_process(name):
     r0, r1 = _run(name, sync_bn=True)
-    rets, ev, st = _single(name)
+    rets, ev, st, single_sweep = _single(name)
     for (a, b, s) in zip(r0[0], r1[0], rets):
         assert np.allclose(a, b, rtol=1e-6, equal_nan=True)          # both ranks report the global-batch metrics
         assert np.allclose(a, s, rtol=2e-5, atol=1e-6, equal_nan=True), (a, s)
     assert np.allclose(r0[1], ev, rtol=2e-5, equal_nan=True)
+    # full-dataset sweeps: each rank walks its half of every global batch, the per-depth sums are all-reduced
+    sw = single_sweep
+    for a, b, s_ in zip(r0[3], r1[3], sw):
+        assert np.allclose(a, b, rtol=1e-6)
+        assert np.allclose(a, s_, rtol=2e-5, atol=1e-5), (a, s_)
     for k in st:
         assert np.allclose(r0[2][k], r1[2][k], rtol=0, atol=0), k        # replicas stay bit-identical
         scale = np.abs(st[k]).max()
@@ -100,7 +130,7 @@ def test_two_ranks_match_single_process(name):
 
 def test_per_replica_batchnorm_differs():
     r0, _ = _run("c3_reduced", sync_bn=False, steps=1)
-    rets, _, st = _single("c3_reduced", steps=1)
+    rets, _, st, _ = _single("c3_reduced", steps=1)
     # per-replica statistics are a different (DataParallel-like) computation: close, but not the same numbers
     assert abs(r0[0][0][0] - rets[0][0]) > 1e-6 * abs(rets[0][0])
     assert np.abs(r0[2]["rm"] - st["rm"]).max() > 0
