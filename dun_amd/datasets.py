@@ -1,7 +1,12 @@
-"""The one synthetic dataset the plumbing config needs (BASELINE.json configs[0]): the toy 'wiggle' regression
-set, regenerated from its closed form (reference: src/datasets/additional_gap_loader.py:226-250).  Loaders that
-download or read image corpora are out of scope."""
+"""Data feeding for the FC configs: the toy 'wiggle' regression set regenerated from its closed
+form (reference: src/datasets/additional_gap_loader.py:226-250), the UCI "gap"/standard split reader over a directory
+in the reference's on-disk layout (src/datasets/UCI_gap_loader.py:12-60; no download: there is no network), and a
+device-resident batch iterator that keeps the epoch loop free of DataLoader workers and host-to-device copies.
+Loaders that download or read image corpora are out of scope."""
+import os
+
 import numpy as np
+import torch
 import torch.utils.data as data
 
 
@@ -34,3 +39,72 @@ class Datafeed(data.Dataset):
 
     def __len__(self):
         return len(self.data)
+
+
+def load_gap_UCI(base_dir, dname, n_split=0, gap=True):
+    """Same returns as the reference's load_gap_UCI: (X_train, X_test, x_means, x_stds, y_train, y_test, y_means,
+    y_stds), features/targets standardised with the TRAIN split's statistics (stds under 1e-10 -> 1).  Reads
+    <base_dir>/UCI_for_sharing/{standard,gap}/<dname>/data/{data,index_features,index_target,index_train_i,
+    index_test_i}.txt; a missing directory raises instead of downloading."""
+    root = os.path.join(base_dir, "UCI_for_sharing")
+    if not os.path.exists(root):
+        raise FileNotFoundError("%s not found (the reference fetches it from the network; place the extracted "
+                                "UCI_for_sharing directory there)" % root)
+    dir_load = os.path.join(root, "standard", dname, "data")
+    dir_idx = os.path.join(root, "gap" if gap else "standard", dname, "data")
+    table = np.loadtxt(os.path.join(dir_load, "data.txt"))
+    feature_idx = np.loadtxt(os.path.join(dir_load, "index_features.txt")).astype(int)
+    target_idx = np.loadtxt(os.path.join(dir_load, "index_target.txt")).astype(int)
+    splits = []
+    for i in range(20):
+        tr, te = (os.path.join(dir_idx, "index_%s_%d.txt" % (k, i)) for k in ("train", "test"))
+        if os.path.exists(tr) and os.path.exists(te):
+            splits.append((np.loadtxt(tr).astype(int), np.loadtxt(te).astype(int)))
+    train_idx, test_idx = splits[n_split]
+    rows_train, rows_test = table[train_idx, :], table[test_idx, :]
+    X_train = rows_train[:, feature_idx].astype(np.float32)
+    X_test = rows_test[:, feature_idx].astype(np.float32)
+    y_train = rows_train[:, target_idx].astype(np.float32)
+    y_test = rows_test[:, target_idx].astype(np.float32)
+    x_means, x_stds = X_train.mean(axis=0), X_train.std(axis=0)
+    y_means, y_stds = y_train.mean(axis=0), y_train.std(axis=0)
+    x_stds[x_stds < 1e-10] = 1.
+    X_train = (X_train - x_means) / x_stds
+    X_test = (X_test - x_means) / x_stds
+    y_train = ((y_train - y_means) / y_stds)[:, np.newaxis]
+    y_test = ((y_test - y_means) / y_stds)[:, np.newaxis]
+    return X_train, X_test, x_means, x_stds, y_train, y_test, y_means, y_stds
+
+
+class DeviceLoader(object):
+    """Batches of a dataset that lives on the device: `for x, y in loader` yields slices (views when not shuffling,
+    one gather per batch when shuffling), `len(loader.dataset)` is the row count the sweeps ask for.  Stands where
+    train_fc_DUN takes a torch DataLoader; `rank`/`world` hand every rank its rows of each global batch."""
+
+    def __init__(self, x, y, batch_size, shuffle=False, device=None, seed=0, drop_last=False, rank=0, world=1):
+        device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+        self.x = torch.as_tensor(x).to(device)
+        self.y = torch.as_tensor(y).to(device)
+        assert self.x.shape[0] == self.y.shape[0]
+        assert batch_size % world == 0, "global batch must split evenly over the ranks"
+        self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
+        self.rank, self.world = rank, world
+        self.dataset = Datafeed(self.x, self.y)
+        self._gen = torch.Generator(device="cpu").manual_seed(seed)  # same permutation on every rank
+
+    def __len__(self):
+        n = self.x.shape[0]
+        return n // self.batch_size if self.drop_last or self.world > 1 else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = self.x.shape[0]
+        perm = torch.randperm(n, generator=self._gen).to(self.x.device) if self.shuffle else None
+        local = self.batch_size // self.world
+        for i in range(len(self)):
+            lo = i * self.batch_size + self.rank * local
+            hi = min(lo + local, n) if self.world > 1 else min((i + 1) * self.batch_size, n)
+            if perm is None:
+                yield self.x[lo:hi], self.y[lo:hi]
+            else:
+                idx = perm[lo:hi]
+                yield self.x[idx], self.y[idx]

@@ -336,9 +336,47 @@ def image_case():
         print("wrote", tag, "fit ret", rets[-1], "D", D)
 
 
+def uci_case():
+    """A tiny synthetic table in the reference's UCI on-disk layout, read by the reference's load_gap_UCI
+    (src/datasets/UCI_gap_loader.py:12-60); raw files and outputs go into uci_small.npz."""
+    import tempfile
+    from src.datasets.UCI_gap_loader import load_gap_UCI
+    rs = np.random.RandomState(42)
+    n, nf = 40, 5
+    table = np.round(rs.randn(n, nf + 1) * np.array([1, 10, 0.1, 3, 1, 2]) + np.array([0, 5, 1, -2, 0, 1]), 4)
+    table[:, 3] = 7.0  # a constant feature: std < 1e-10 -> 1
+    feat, targ = np.array([0, 1, 3, 4, 5]), np.array(2)
+    out = {"table": table, "feature_idx": feat, "target_idx": targ}
+    with tempfile.TemporaryDirectory() as tmp:
+        for kind in ("standard", "gap"):
+            d = os.path.join(tmp, "UCI_for_sharing", kind, "toy", "data")
+            os.makedirs(d)
+            if kind == "standard":
+                np.savetxt(os.path.join(d, "data.txt"), table)
+                np.savetxt(os.path.join(d, "index_features.txt"), feat, fmt="%d")
+                np.savetxt(os.path.join(d, "index_target.txt"), targ.reshape(1), fmt="%d")
+            for i in range(3):
+                perm = rs.permutation(n)
+                k = 30 if kind == "standard" else 26
+                out["%s_train_%d" % (kind, i)], out["%s_test_%d" % (kind, i)] = perm[:k], perm[k:]
+                np.savetxt(os.path.join(d, "index_train_%d.txt" % i), perm[:k], fmt="%d")
+                np.savetxt(os.path.join(d, "index_test_%d.txt" % i), perm[k:], fmt="%d")
+        names = ["X_train", "X_test", "x_means", "x_stds", "y_train", "y_test", "y_means", "y_stds"]
+        for gap in (True, False):
+            for sp in (0, 2):
+                res = load_gap_UCI(tmp, "toy", n_split=sp, gap=gap)
+                for nm, v in zip(names, res):
+                    out["out/%s/%d/%s" % ("gap" if gap else "standard", sp, nm)] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, "uci_small.npz"), **out)
+    print("wrote uci_small")
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "image":
         image_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "uci":
+        uci_case()
         return
     base = dict(seed=0, O=1, vi=True, regression=True, wd=0.0)
     X, Y = load_wiggle()
@@ -366,6 +404,7 @@ def main():
     edge_cases()
     head_case()
     image_case()
+    uci_case()
 
 
 if __name__ == "__main__":

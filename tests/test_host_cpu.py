@@ -164,3 +164,60 @@ def test_train_fc_loop_plumbing(cpu_backend, tmp_path):
                  cuda=False, regression=True)
     quiet(net2.load, os.path.join(basedir, "models", "theta_last.dat"))
     assert net2.epoch >= 1
+
+
+# ------------------------------------------------------------------------------------------------------
+# data feeding
+# ------------------------------------------------------------------------------------------------------
+def _write_uci_dir(z, root):
+    import os
+    for kind in ("standard", "gap"):
+        d = os.path.join(root, "UCI_for_sharing", kind, "toy", "data")
+        os.makedirs(d)
+        if kind == "standard":
+            np.savetxt(os.path.join(d, "data.txt"), z["table"])
+            np.savetxt(os.path.join(d, "index_features.txt"), z["feature_idx"], fmt="%d")
+            np.savetxt(os.path.join(d, "index_target.txt"), z["target_idx"].reshape(1), fmt="%d")
+        for i in range(3):
+            np.savetxt(os.path.join(d, "index_train_%d.txt" % i), z["%s_train_%d" % (kind, i)], fmt="%d")
+            np.savetxt(os.path.join(d, "index_test_%d.txt" % i), z["%s_test_%d" % (kind, i)], fmt="%d")
+
+
+def test_load_gap_uci_matches_reference_loader(tmp_path):
+    """uci_small.npz: a synthetic table in the UCI layout and what the reference's load_gap_UCI returned for it."""
+    import os
+    from dun_amd.datasets import load_gap_UCI
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "uci_small.npz"))
+    _write_uci_dir(z, str(tmp_path))
+    names = ["X_train", "X_test", "x_means", "x_stds", "y_train", "y_test", "y_means", "y_stds"]
+    for kind, gap in (("gap", True), ("standard", False)):
+        for sp in (0, 2):
+            res = load_gap_UCI(str(tmp_path), "toy", n_split=sp, gap=gap)
+            for nm, v in zip(names, res):
+                ref = z["out/%s/%d/%s" % (kind, sp, nm)]
+                assert np.asarray(v).dtype == ref.dtype and np.array_equal(np.asarray(v), ref), (kind, sp, nm)
+    with pytest.raises(FileNotFoundError):
+        load_gap_UCI(str(tmp_path / "nowhere"), "toy")
+
+
+def test_device_loader_batches_and_rank_shards():
+    from dun_amd.datasets import DeviceLoader
+    x = torch.arange(50, dtype=torch.float32).view(25, 2)
+    y = torch.arange(25, dtype=torch.float32).view(25, 1)
+    dl = DeviceLoader(x, y, batch_size=8, device="cpu")
+    got = list(dl)
+    assert len(dl) == 4 and len(dl.dataset) == 25 and [b[0].shape[0] for b in got] == [8, 8, 8, 1]
+    assert torch.equal(torch.cat([b[1] for b in got]), y)
+    # shuffled: a permutation of the rows, x and y stay aligned, epochs differ
+    dl = DeviceLoader(x, y, batch_size=8, shuffle=True, device="cpu", seed=3)
+    e1 = torch.cat([b[1] for b in dl]).view(-1)
+    e2 = torch.cat([b[1] for b in dl]).view(-1)
+    assert sorted(e1.tolist()) == list(range(25)) and not torch.equal(e1, e2)
+    for xb, yb in dl:
+        assert torch.equal(xb[:, 0], 2 * yb[:, 0])
+    # two ranks: the halves of each global batch, same permutation on both ranks, ragged tail dropped
+    parts = [list(DeviceLoader(x, y, batch_size=8, shuffle=True, device="cpu", seed=5, rank=r, world=2)) for r in (0, 1)]
+    full = list(DeviceLoader(x, y, batch_size=8, shuffle=True, device="cpu", seed=5, drop_last=True))
+    assert len(parts[0]) == len(parts[1]) == len(full) == 3
+    for b0, b1, bf in zip(parts[0], parts[1], full):
+        assert torch.equal(torch.cat([b0[1], b1[1]]), bf[1])

@@ -309,3 +309,26 @@ def test_graphed_step_is_bit_identical_to_eager(name, monkeypatch):
     assert torch.equal(net.model.num_batches_tracked, eager.model.num_batches_tracked)
     assert torch.equal(net.prob_model.current_posterior, eager.prob_model.current_posterior)
     assert np.array_equal(np.array(net.eval(x, y)), np.array(want_eval), equal_nan=True)
+
+
+def test_train_fc_epoch_loop_on_device_loader(tmp_path):
+    """Config-1 end to end on the GPU: the reference-shaped epoch loop over a device-resident loader."""
+    from dun_amd.datasets import DeviceLoader, load_wiggle
+    from dun_amd.probability import depth_categorical_VI
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_resnet
+    from dun_amd.train_fc import train_fc_DUN
+    from dun_amd.training_wrappers import DUN_VI
+    X, Y = load_wiggle()
+    train = DeviceLoader(X, Y, batch_size=128, shuffle=True, device="cuda", seed=0)
+    val = DeviceLoader(X, Y, batch_size=128, device="cuda")
+    torch.manual_seed(0)
+    model = arq_uncert_fc_resnet(1, 1, 100, 10)
+    net = quiet(DUN_VI, model, depth_categorical_VI([1.0 / 11] * 11, cuda=True), 300, lr=1e-3, momentum=0.9,
+                weight_decay=1e-4, cuda=True, regression=True)
+    out = quiet(train_fc_DUN, net, "t", str(tmp_path), 128, 12, train, val, True, seed=0, nb_its_dev=3,
+                track_posterior=True, track_exact_ELBO=True, save_freq=6, q_nograd_its=2)
+    elbo, nll_tr, nll_dev, err_tr, err_dev, q_app, q_true, lik, exact, basedir = out
+    assert np.all(np.isfinite(elbo)) and elbo[-1] > elbo[0]
+    assert np.all(np.isfinite(exact)) and exact[-1] > exact[0]
+    assert err_tr[-1] < err_tr[0]
+    assert q_app.shape == (12, 11) and abs(q_app[-1].sum() - 1) < 1e-5 and abs(q_true[-1].sum() - 1) < 1e-4
