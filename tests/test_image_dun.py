@@ -106,3 +106,30 @@ def test_image_dun_gpu(name):
     assert rel_err(net2.predict(x).cpu(), c["pred"]) < 0.1
     net2.prob_model.current_posterior = c.t("fast_pred_q").cuda()
     assert rel_err(quiet(net2.fast_predict, x).cpu(), c["fast_pred"]) < 0.1
+
+
+@pytest.mark.gpu
+def test_image_epoch_loop_trains_checkpoints_and_resumes(tmp_path):
+    """train_img.train_loop (reference: experiments/image/train_DUN.py:145-248) on a tiny synthetic MNIST-shaped set."""
+    from dun_amd.train_img import make_image_dun, train_loop
+    torch.manual_seed(0)
+    net = quiet(make_image_dun, dataset="MNIST", model="resnet18", start_depth=1, end_depth=5, lr=0.05,
+                milestones=[2], cuda=True)
+    torch.backends.cudnn.benchmark = False
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(96, 1, 28, 28, generator=g)
+    y = (x.mean(dim=(1, 2, 3)) > 0).long() + 2 * (x[:, 0, :14].mean(dim=(1, 2)) > 0).long()   # learnable 4-class labels
+    batches = [(x[i:i + 32], y[i:i + 32]) for i in range(0, 96, 32)]
+    out = quiet(train_loop, net, batches, batches[:1], 96, epochs=3, savedir=str(tmp_path), q_nograd_its=1)
+    elbo, err_tr, nll_tr, err_dev, nll_dev, best = out
+    assert np.all(np.isfinite(elbo)) and np.all(np.isfinite(nll_tr)) and np.all(np.isfinite(nll_dev))
+    assert elbo[-1] > elbo[0] and nll_tr[-1] < nll_tr[0]
+    assert net.epoch == 3 and abs(net.optimizer.param_groups[0]["lr"] - 0.005) < 1e-12   # milestone at epoch 2
+    assert os.path.exists(os.path.join(str(tmp_path), "checkpoint.pth.tar"))
+    assert os.path.exists(os.path.join(str(tmp_path), "stats_array.pkl"))
+    # resume: two more epochs continue the arrays from the checkpointed epoch
+    net2 = quiet(make_image_dun, dataset="MNIST", model="resnet18", start_depth=1, end_depth=5, lr=0.05,
+                 milestones=[2], cuda=True)
+    out2 = quiet(train_loop, net2, batches, batches[:1], 96, epochs=5, savedir=str(tmp_path),
+                 resume=os.path.join(str(tmp_path), "checkpoint.pth.tar"))
+    assert net2.epoch == 5 and np.allclose(out2[0][:3], elbo) and np.all(out2[0][3:] != 0)
