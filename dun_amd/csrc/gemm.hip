@@ -126,11 +126,39 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][
     double s1[MI], s2[MI];
 #pragma unroll
     for (int ni = 0; ni < MI; ++ni) s1[ni] = s2[ni] = 0.0;
+    // Addends first, stores later.  R may BE C (the running gradient is updated in place), so the compiler cannot
+    // move a residual load above an earlier store of this thread and would pay one HBM round trip per element; every
+    // element is read and written by its own thread only, so gathering all of them up front is safe.
+    const bool has_r = p.R != nullptr, has_u1 = p.U != nullptr && p.O == 1;
+    float rr[MI][MI][16], uu[MI][16];
+    if (has_r) {
+#pragma unroll
+        for (int ni = 0; ni < MI; ++ni) {
+            const int col = n0 + wc * WT + ni * 32 + li;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wr * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    rr[mi][ni][r] = (FULL || (row < p.M && col < p.N)) ? p.R[(size_t)row * p.ldr + col] : 0.f;
+                }
+        }
+    }
+    if (has_u1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                uu[mi][r] = (FULL || row < p.M) ? p.U[row] : 0.f;
+            }
+    }
 #pragma unroll
     for (int ni = 0; ni < MI; ++ni) {
         const int col = n0 + wc * WT + ni * 32 + li;
         const bool col_ok = FULL || col < p.N;
         const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+        const float v1 = (has_u1 && col_ok) ? p.V[col] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -139,8 +167,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][
                 if (FULL || (row < p.M && col_ok)) {
                     float v = acc[mi][ni][r] + bv;
                     if (p.relu) v = v > 0.f ? v : 0.f;
-                    if (p.R != nullptr) v += p.R[(size_t)row * p.ldr + col];
-                    if (p.U != nullptr) {
+                    if (has_r) v += rr[mi][ni][r];
+                    if (has_u1) {
+                        v += uu[mi][r] * v1;
+                    } else if (p.U != nullptr) {
                         for (int o = 0; o < p.O; ++o) v += p.U[(size_t)row * p.O + o] * p.V[(size_t)o * p.ldv + col];
                     }
                     p.C[(size_t)row * p.ldc + col] = v;
@@ -382,11 +412,193 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmP p) {
     gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Four-stage variant of the LDS-DMA kernel.  The two-buffer kernel above ends every 32-deep K tile with a barrier that
+// every wave reaches with an EMPTY matrix pipe (its MFMAs are issued, the next tile's fragments cannot be read before
+// the barrier), so each tile pays barrier skew + an LDS round trip.  Here the K loop advances in 16-deep half tiles
+// through a ring of four 16 KiB stages (same 64 KiB, still two workgroups per CU) and the barrier sits in the MIDDLE
+// of a half tile, behind 16 issued MFMAs:
+//     half j:   [read frags (j, group 1)]  16 MFMAs (j, group 0)
+//               wait for the DMA of half j+1 (issued two half tiles ago; counted vmcnt, half j+2 stays in flight)
+//               s_barrier          -> half j+1 is visible to all waves; all waves are done reading half j-1
+//               DMA half j+3 -> stage (j+3)&3 (the stage of half j-1)
+//               [read frags (j+1, group 0)]  16 MFMAs (j, group 1)
+// so no wave ever crosses a tile boundary with nothing to issue.  Images: K-contiguous [128][16] (64-B rows, 16-B chunk
+// index XOR (row>>1)&3 on the source address and on the read), M/N-contiguous [16][128].
+// ---------------------------------------------------------------------------------------------------------
+constexpr int HK = 16;                 // K depth of a half tile
+constexpr int HALF_TILE = BM * HK;     // 2048 floats = 8 KiB per operand
+constexpr int STAGE = 2 * HALF_TILE;   // A image | B image
+
+// The DMA goes through buffer_load ... lds (MUBUF), not global_load_lds: the compiler treats a pending FLAT-encoded
+// LDS-DMA as "may be an LDS access" and then flushes lgkmcnt to 0 at every LDS wait, which would serialise the
+// fragment prefetch behind the MFMAs it is supposed to hide under; with MUBUF it emits counted lgkmcnt waits.
+// A raw buffer descriptor addresses 4 GiB from the operand's base with a 32-bit byte offset (checked on the host);
+// its num_records bound makes an out-of-range lane read zeros instead of faulting.
+struct DmaOp {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[2];  // per-lane byte offsets of the wave's two 1 KiB pieces at k0 = 0
+    int kstep;    // bytes per unit of k0
+};
+
+template <bool KC>
+__device__ __forceinline__ DmaOp dma_setup(const float* P, int ld, int r0, int rows, int K, int wave, int lane) {
+    DmaOp d;
+    const long long extent = KC ? ((long long)(rows - 1) * ld + K) * 4 : ((long long)(K - 1) * ld + rows) * 4;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, (int)extent, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = wave * 2 + j;
+        if (KC) {
+            const int row = piece * 16 + (lane >> 2), pc = lane & 3;
+            const int c = pc ^ ((row >> 1) & 3);
+            d.voff[j] = ((r0 + row) * ld + c * 4) * 4;
+        } else {
+            const int k = piece * 2 + (lane >> 5), col = (lane & 31) * 4;
+            d.voff[j] = (k * ld + r0 + col) * 4;
+        }
+    }
+    d.kstep = KC ? 4 : ld * 4;
+    return d;
+}
+
+__device__ __forceinline__ void dma_half(const DmaOp& d, int k0, float* lds, int wave) {
+    const int soff = k0 * d.kstep;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc, (__attribute__((address_space(3))) void*)(lds + (wave * 2 + j) * 256),
+                                                 16, d.voff[j], soff, 0, 0);
+}
+
+// fragment of k group t (0/1) of a half tile: element e of lane (row, h) is operand[row][8t + 4h + e]
+template <bool KC>
+__device__ __forceinline__ void read_frag_half(const float* lds, int row, int t, int h, float (&f)[4]) {
+    if (KC) {
+        const int pc = (2 * t + h) ^ ((row >> 1) & 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * HK + pc * 4);
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = lds[(8 * t + 4 * h + e) * BM + row];
+    }
+}
+
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt = bits [3:0] and [15:14]; expcnt / lgkmcnt fields left at "no wait")
+#define DUN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * STAGE];
+
+    const int nwg = p.gridM * p.gridN;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.gridN, bn = bid % p.gridN;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nh = p.K / HK;  // >= 2 (K % 32 == 0)
+    const DmaOp dA = dma_setup<A_KC>(p.A, p.lda, m0, p.M, p.K, wave, lane);
+    const DmaOp dB = dma_setup<B_KC>(p.B, p.ldb, n0, p.N, p.K, wave, lane);
+    // prologue: halves 0..2 in flight (4 DMA instructions per half and wave), half 0 landed and visible
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < nh) {
+            dma_half(dA, j * HK, smem + j * STAGE, wave);
+            dma_half(dB, j * HK, smem + j * STAGE + HALF_TILE, wave);
+        }
+    }
+    if (nh >= 3) DUN_WAIT_VMCNT(8); else DUN_WAIT_VMCNT(4);
+    __builtin_amdgcn_s_barrier();
+
+    // Every kernel argument the epilogue needs is pulled into SGPRs HERE: a scalar (kernel-argument) load still
+    // pending at the loop entry shares lgkmcnt with the LDS reads, the counter is then no longer in-order for the
+    // compiler, and it would wait for lgkmcnt(0) -- i.e. for the prefetch just issued -- at every MFMA group.
+    asm volatile("" ::"s"(p.C), "s"(p.bias), "s"(p.R), "s"(p.U), "s"(p.V), "s"(p.colstats), "s"(p.M), "s"(p.N),
+                 "s"(p.ldc), "s"(p.ldr), "s"(p.O), "s"(p.ldv), "s"(p.relu), "s"(p.gridM));
+
+    float fa[2][2][4], fb[2][2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) read_frag_half<A_KC>(smem, wr * 64 + mi * 32 + li, 0, h, fa[0][mi]);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) read_frag_half<B_KC>(smem + HALF_TILE, wc * 64 + ni * 32 + li, 0, h, fb[0][ni]);
+
+    // One half tile.  NEXT: half j+1 exists; INFLIGHT: half j+2 was issued (so it may stay in flight); ISSUE: half j+3
+    // exists.  Compile-time flags: a run-time branch around the fragment prefetch would make the compiler wait for
+    // ALL outstanding LDS reads at the join, i.e. for the prefetch itself.
+#define DUN_HALF_STEP(J, NEXT, INFLIGHT, ISSUE)                                                                        \
+    do {                                                                                                               \
+        const float* a_s = smem + ((J) & 3) * STAGE;                                                                   \
+        const float* b_s = a_s + HALF_TILE;                                                                            \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                               \
+            read_frag_half<A_KC>(a_s, wr * 64 + mi * 32 + li, 1, h, fa[1][mi]);                                        \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                               \
+            read_frag_half<B_KC>(b_s, wc * 64 + ni * 32 + li, 1, h, fb[1][ni]);                                        \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch IN FRONT of the MFMAs it hides under */                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][mi][e], fb[0][ni][e], acc[mi][ni], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (NEXT) {                                                                                                    \
+            if (INFLIGHT) DUN_WAIT_VMCNT(4); else DUN_WAIT_VMCNT(0);                                                   \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            if (ISSUE) {                                                                                               \
+                float* st = smem + (((J) + 3) & 3) * STAGE; /* stage of half J-1: every wave is past its last read */  \
+                dma_half(dA, ((J) + 3) * HK, st, wave);                                                                \
+                dma_half(dB, ((J) + 3) * HK, st + HALF_TILE, wave);                                                    \
+            }                                                                                                          \
+            const float* a_n = smem + (((J) + 1) & 3) * STAGE;                                                         \
+            const float* b_n = a_n + HALF_TILE;                                                                        \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+                read_frag_half<A_KC>(a_n, wr * 64 + mi * 32 + li, 0, h, fa[0][mi]);                                    \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                           \
+                read_frag_half<B_KC>(b_n, wc * 64 + ni * 32 + li, 0, h, fb[0][ni]);                                    \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][mi][e], fb[1][ni][e], acc[mi][ni], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    } while (0)
+
+    int j = 0;
+    for (; j + 3 < nh; ++j) DUN_HALF_STEP(j, true, true, true);   // steady state
+    if (j + 2 < nh) { DUN_HALF_STEP(j, true, true, false); ++j; }  // half nh-3: nothing left to issue
+    if (j + 1 < nh) { DUN_HALF_STEP(j, true, false, false); ++j; } // half nh-2: the last DMA must land
+    DUN_HALF_STEP(j, false, false, false);                         // half nh-1
+#undef DUN_HALF_STEP
+    __syncthreads();  // the epilogue reuses the LDS for the column statistics
+    gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+}
+
+// A/B hook: DUN_GEMM_DMA2=1 keeps tile-aligned problems on the two-buffer LDS-DMA kernel
+static const bool g_dma_two_buffer = getenv("DUN_GEMM_DMA2") != nullptr && getenv("DUN_GEMM_DMA2")[0] == '1';
+
 template <bool A_KC, bool B_KC>
 static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream_t s) {
     const int grid = p.gridM * p.gridN;
-    if (dma)
+    // the four-stage kernel addresses its operands with 32-bit byte offsets from their bases
+    const bool fits32 = (long long)(A_KC ? p.M : p.K) * p.lda * 4 < (1ll << 31) &&
+                        (long long)(B_KC ? p.N : p.K) * p.ldb * 4 < (1ll << 31);
+    if (dma && (g_dma_two_buffer || !fits32))
         hipLaunchKernelGGL((gemm_f32_dma_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
+    else if (dma)
+        hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
     else if (small && vec)
         hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 1>), dim3(grid), dim3(256), 0, s, p);
     else if (small)
