@@ -158,13 +158,17 @@ def kernel_rooflines(net, B_local, reps):
     flops = 2.0 * B_local * W * W
     scratch = torch.empty_like(Z0)
     ms = timed(lambda: be.gemm(H0, w0, B_local, W, W, bias=b0, relu=True, colstats=True, out=scratch), reps)
-    out["gemm_fwd"] = dict(kernel="gemm_f32_dma_kernel<A_KC=1,B_KC=1> (block forward: bias+ReLU+BN stats)",
+    out["gemm_fwd"] = dict(kernel="gemm_f32_dma4_kernel<A_KC=1,B_KC=1> (block forward: bias+ReLU+BN stats)",
                            ms=ms, tflops=flops / ms / 1e9)
-    ms = timed(lambda: be.gemm(Z0, w0, B_local, W, W, a_kcontig=True, b_kcontig=False, R=scratch, out=scratch), reps)
-    out["gemm_dx"] = dict(kernel="gemm_f32_dma_kernel<A_KC=1,B_KC=0> (dX = dU W + g)", ms=ms, tflops=flops / ms / 1e9)
+    u1 = torch.randn(B_local, 1, device=Z0.device) * 1e-3
+    v1 = model.stacked["w_out"]
+    ms = timed(lambda: be.gemm(Z0, w0, B_local, W, W, a_kcontig=True, b_kcontig=False, R=scratch, U=u1, V=v1,
+                               out=scratch), reps)
+    out["gemm_dx"] = dict(kernel="gemm_f32_dma4_kernel<A_KC=1,B_KC=0> (dX = dU W + g + dact w_out, in place)", ms=ms, tflops=flops / ms / 1e9)
     gw = model.stacked_grad["w"][0]
-    ms = timed(lambda: be.gemm(Z0, H0, W, W, B_local, a_kcontig=False, b_kcontig=False, out=gw), reps)
-    out["gemm_dw"] = dict(kernel="gemm_f32_dma_kernel<A_KC=0,B_KC=0> (dW = dU^T H)", ms=ms, tflops=flops / ms / 1e9)
+    skws = torch.empty(2 * W * W, device=Z0.device)
+    ms = timed(lambda: be.gemm(Z0, H0, W, W, B_local, a_kcontig=False, b_kcontig=False, out=gw, splitk_ws=skws), reps)
+    out["gemm_dw"] = dict(kernel="gemm_f32_dma4_kernel<A_KC=0,B_KC=0>, split-K 2 + splitk_sum (dW = dU^T H)", ms=ms, tflops=flops / ms / 1e9)
     # head over all D*B hidden rows (O=1): reads 4*D*B*W bytes once
     Hall = buf.H.view(D * B_local, W)
     ms = timed(lambda: be.head_forward(Hall, model.stacked["w_out"], model.stacked["b_out"]), reps)

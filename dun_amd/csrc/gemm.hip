@@ -39,6 +39,8 @@ struct GemmP {
     int O, ldv;
     double* colstats;
     int gridM, gridN;
+    int ksplit;   // > 1: blockIdx.y takes K range [y*K/ksplit, (y+1)*K/ksplit) and stores its raw sum to part[y]
+    float* part;  // [ksplit][M][N]
 };
 
 // ---- global -> register staging of one operand tile: 4 x float4 per thread ----
@@ -510,15 +512,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nh = p.K / HK;  // >= 2 (K % 32 == 0)
+    const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * (p.K / p.ksplit) : 0;
+    const int nh = (p.ksplit > 1 ? p.K / p.ksplit : p.K) / HK;  // >= 2 (K range % 32 == 0)
     const DmaOp dA = dma_setup<A_KC>(p.A, p.lda, m0, p.M, p.K, wave, lane);
     const DmaOp dB = dma_setup<B_KC>(p.B, p.ldb, n0, p.N, p.K, wave, lane);
     // prologue: halves 0..2 in flight (4 DMA instructions per half and wave), half 0 landed and visible
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         if (j < nh) {
-            dma_half(dA, j * HK, smem + j * STAGE, wave);
-            dma_half(dB, j * HK, smem + j * STAGE + HALF_TILE, wave);
+            dma_half(dA, kbeg + j * HK, smem + j * STAGE, wave);
+            dma_half(dB, kbeg + j * HK, smem + j * STAGE + HALF_TILE, wave);
         }
     }
     if (nh >= 3) DUN_WAIT_VMCNT(8); else DUN_WAIT_VMCNT(4);
@@ -558,8 +561,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
             __builtin_amdgcn_s_barrier();                                                                              \
             if (ISSUE) {                                                                                               \
                 float* st = smem + (((J) + 3) & 3) * STAGE; /* stage of half J-1: every wave is past its last read */  \
-                dma_half(dA, ((J) + 3) * HK, st, wave);                                                                \
-                dma_half(dB, ((J) + 3) * HK, st + HALF_TILE, wave);                                                    \
+                dma_half(dA, kbeg + ((J) + 3) * HK, st, wave);                                                         \
+                dma_half(dB, kbeg + ((J) + 3) * HK, st + HALF_TILE, wave);                                             \
             }                                                                                                          \
             const float* a_n = smem + (((J) + 1) & 3) * STAGE;                                                         \
             const float* b_n = a_n + HALF_TILE;                                                                        \
@@ -583,9 +586,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     DUN_HALF_STEP(j, false, false, false);                         // half nh-1
 #undef DUN_HALF_STEP
     __syncthreads();  // the epilogue reuses the LDS for the column statistics
-    gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    if (p.ksplit > 1) {
+        GemmP q = p;  // raw partial sum of this K range; splitk_sum_kernel adds the ranges in order
+        q.C = p.part + (size_t)blockIdx.y * p.M * p.N;
+        q.ldc = p.N;
+        q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr;
+        gemm_epilogue<true, 2>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    } else {
+        gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    }
 }
 
+// C[m][n] = part[0][m][n] + part[1][m][n] + ... (fixed order: reproducible)
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ part, int ksplit, int M, int N,
+                                                         float* __restrict__ C, int ldc) {
+    const size_t n4 = (size_t)M * N / 4;  // N % 128 == 0
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
+        for (int k = 1; k < ksplit; ++k) v += reinterpret_cast<const f32x4*>(part + (size_t)k * M * N)[i];
+        const size_t e = i * 4;
+        const int m = (int)(e / N), n = (int)(e % N);
+        *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+    }
+}
+
+// A/B hook: DUN_GEMM_NO_SPLITK=1 keeps long-K problems on one workgroup per tile
+static const bool g_no_splitk = getenv("DUN_GEMM_NO_SPLITK") != nullptr && getenv("DUN_GEMM_NO_SPLITK")[0] == '1';
 // A/B hook: DUN_GEMM_DMA2=1 keeps tile-aligned problems on the two-buffer LDS-DMA kernel
 static const bool g_dma_two_buffer = getenv("DUN_GEMM_DMA2") != nullptr && getenv("DUN_GEMM_DMA2")[0] == '1';
 
@@ -597,7 +623,13 @@ static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream
                         (long long)(B_KC ? p.N : p.K) * p.ldb * 4 < (1ll << 31);
     if (dma && (g_dma_two_buffer || !fits32))
         hipLaunchKernelGGL((gemm_f32_dma_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
-    else if (dma)
+    else if (dma && p.ksplit > 1) {
+        hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+        DUN_LAUNCH_CHECK();
+        const size_t n4 = (size_t)p.M * p.N / 4;
+        const int g = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_sum_kernel, dim3(g), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
+    } else if (dma)
         hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
     else if (small && vec)
         hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 1>), dim3(grid), dim3(256), 0, s, p);
@@ -653,6 +685,20 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     const bool vec = va && vb;
     // whole tiles only: LDS-DMA cannot zero-fill, ragged problems take the register-staged kernel
     const bool dma = !small && vec && d->M % BM == 0 && d->N % BN == 0 && d->K % BK == 0 && !g_force_generic;
+    // One workgroup per CU cannot hide its own barriers: an epilogue-free problem with fewer tiles than 2 x 256 CUs and
+    // a long K (dW = dU^T H: 256 tiles, K = batch) runs two K ranges per tile and adds them in a fixed order.
+    p.ksplit = 1;
+    p.part = nullptr;
+    const long long tiles = (long long)p.gridM * p.gridN;
+    const bool plain = !d->bias && !d->relu && !d->R && !d->U && !d->colstats;
+    const bool fits32 = (long long)(d->a_kcontig ? d->M : d->K) * d->lda * 4 < (1ll << 31) &&
+                        (long long)(d->b_kcontig ? d->N : d->K) * d->ldb * 4 < (1ll << 31);
+    if (dma && plain && fits32 && !g_dma_two_buffer && !g_no_splitk && tiles < 512 && d->K % 64 == 0 && d->K >= 2048 &&
+        d->splitk_ws != nullptr && d->splitk_ws_floats >= 2ull * d->M * d->N && aligned16(d->splitk_ws) &&
+        aligned16(d->C) && d->ldc % 4 == 0) {
+        p.ksplit = 2;
+        p.part = d->splitk_ws;
+    }
     if (d->a_kcontig) {
         if (d->b_kcontig) return launch_gemm<true, true>(p, vec, dma, small, s);
         return launch_gemm<true, false>(p, vec, dma, small, s);

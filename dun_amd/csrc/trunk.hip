@@ -478,6 +478,7 @@ static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipS
     g.B = Hd(c, i); g.ldb = W; g.b_kcontig = 0;
     g.C = c->g.w + (size_t)i * W * W; g.ldc = W;
     g.M = W; g.N = W; g.K = B;
+    g.splitk_ws = c->ws; g.splitk_ws_floats = c->ws_floats;  // the bias partials in ws were consumed just above
     int rc = gemm_f32(&g, s);
     if (rc) return rc;
     // g <- [g +] dU W_i + dact_i w_out   (in place: every element is read and written by its own thread)
@@ -522,7 +523,10 @@ extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
     const size_t P = (size_t)ceil_div(B, 64);  // upper bound of the GEMM's row tiles (and of num_slabs(B))
     const size_t cols = 4 * P * (size_t)W;  // fp64 [2][P][W] forward statistics partials
     const size_t hb = head_backward_ws((L + 1) * B, W, O);
-    return (cols > hb ? cols : hb) + 64;
+    const size_t sk = L > 0 ? 2 * (size_t)W * W : 0;  // split-K partials of dW = dU^T H
+    size_t m = cols > hb ? cols : hb;
+    if (sk > m) m = sk;
+    return m + 64;
 }
 
 #define STREAM static_cast<hipStream_t>(stream)

@@ -213,7 +213,7 @@ class HipBackend(object):
 
     # ---- raw GEMM (tests / benchmarks) ----------------------------------------------------------------
     def gemm(self, A, B, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, relu=False, R=None, U=None, V=None,
-             colstats=False, out=None):
+             colstats=False, out=None, splitk_ws=None):
         dev = A.device
         Cm = out if out is not None else torch.empty(M, N, device=dev, dtype=torch.float32)
         d = L.GemmDesc()
@@ -231,6 +231,8 @@ class HipBackend(object):
         if colstats:
             stats = torch.empty(2, L.lib().dun_gemm_colstat_tiles(M, N), N, device=dev, dtype=torch.float64)
             d.colstats = L.ptr(stats)
+        if splitk_ws is not None:
+            d.splitk_ws, d.splitk_ws_floats = L.f32(splitk_ws), splitk_ws.numel()
         L.check(L.lib().dun_gemm_f32(C.byref(d), L.stream_ptr(dev)), "dun_gemm_f32")
         return (Cm, stats) if colstats else Cm
 

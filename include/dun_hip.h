@@ -119,6 +119,8 @@ typedef struct dun_gemm_desc {
     const float* V;
     int O, ldv;
     double* colstats;  /* NULL, or fp64 [2][T][N], T = dun_gemm_colstat_tiles(M, N): per row-tile column sums of C, C^2 */
+    float* splitk_ws;  /* NULL, or scratch of splitk_ws_floats floats: lets an epilogue-free problem with few output */
+    size_t splitk_ws_floats; /* tiles and a long K (dW = dU^T H) split K over two workgroups per tile; >= 2*M*N to be used */
 } dun_gemm_desc;
 int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream);
 /* Row tiles the kernel uses for an M x N problem (128-row tiles; 64-row tiles when the problem is too small to fill

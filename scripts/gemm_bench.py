@@ -15,6 +15,7 @@ b = torch.randn(W, device="cuda", generator=g)
 out = torch.empty(B, W, device="cuda")
 gw = torch.empty(W, W, device="cuda")
 fl = 2.0 * B * W * W
+skws = torch.empty(2 * W * W, device="cuda")
 u1 = torch.randn(B, 1, device="cuda", generator=g) * 1e-3
 v1 = torch.randn(1, W, device="cuda", generator=g)
 for rep in range(2):
@@ -24,6 +25,8 @@ for rep in range(2):
     print("dX   %.3f ms  %.1f TF  (in-place residual + rank-1 head term, as in the step)" % (ms, fl / ms / 1e9))
     ms = timed(lambda: be.gemm(Z, H, W, W, B, a_kcontig=False, b_kcontig=False, out=gw), 10)
     print("dW   %.3f ms  %.1f TF" % (ms, fl / ms / 1e9), flush=True)
+    ms = timed(lambda: be.gemm(Z, H, W, W, B, a_kcontig=False, b_kcontig=False, out=gw, splitk_ws=skws), 10)
+    print("dW   %.3f ms  %.1f TF  (split-K workspace given, as in the step)" % (ms, fl / ms / 1e9), flush=True)
     # epilogue-free variants (what the K loop alone reaches)
     ms = timed(lambda: be.gemm(H, w, B, W, W, out=out), 10)
     print("fwd (no epilogue)  %.3f ms  %.1f TF" % (ms, fl / ms / 1e9))

@@ -67,9 +67,9 @@ def med(d):
 
 # bench.py's roofline names -> substring of the kernel symbol that runs it in the training step
 ROLE = {
-    "gemm_fwd": "gemm_f32_dma_kernel<true, true>",
-    "gemm_dx": "gemm_f32_dma_kernel<true, false>",
-    "gemm_dw": "gemm_f32_dma_kernel<false, false>",
+    "gemm_fwd": "gemm_f32_dma4_kernel<true, true>",
+    "gemm_dx": "gemm_f32_dma4_kernel<true, false>",
+    "gemm_dw": "gemm_f32_dma4_kernel<false, false>",
     "head_fwd": "head_fwd_kernel",
     "head_bwd": "head_bwd_kernel",
     "elbo": "ll_gauss_kernel",

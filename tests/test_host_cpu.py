@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libdun_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.dun_abi_version() >= 1
+    assert lib.dun_abi_version() >= 2
 
 
 def test_no_cpu_fallback_in_product_backend():

@@ -53,6 +53,30 @@ def test_gemm_layouts(be, M, N, K, a_kc, b_kc):
     assert (C.double() - ref).abs().max().item() <= 4e-7 * bound + 1e-30
 
 
+@pytest.mark.parametrize("a_kc", [True, False])
+@pytest.mark.parametrize("b_kc", [True, False])
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 4096), (2048, 2048, 2048)])
+def test_gemm_split_k(be, M, N, K, a_kc, b_kc):
+    """Few tiles + long K + a workspace: two K ranges per tile, summed in a fixed order (the dW = dU^T H shape)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    A_st = dev(A if a_kc else A.t().contiguous())
+    B_st = dev(B.t().contiguous() if b_kc else B)
+    ws = torch.empty(2 * M * N, device="cuda")
+    C1 = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc, splitk_ws=ws)
+    C2 = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc, splitk_ws=ws)
+    C0 = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc)
+    assert torch.equal(C1, C2)                                   # reproducible
+    ref = A.double() @ B.double()
+    bound = (A.abs().double() @ B.abs().double()).max().item()
+    assert (C1.cpu().double() - ref).abs().max().item() <= 4e-7 * bound
+    assert (C0.cpu().double() - ref).abs().max().item() <= 4e-7 * bound
+    # a workspace that is too small is simply not used
+    C3 = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc, splitk_ws=torch.empty(16, device="cuda"))
+    assert torch.equal(C3, C0)
+
+
 @pytest.mark.parametrize("M,N,K,O", [(256, 128, 64, 1), (300, 100, 100, 1), (130, 200, 36, 3), (512, 256, 256, 10),
                                      (2048, 1024, 64, 2), (2050, 1030, 70, 1)])
 def test_gemm_epilogues(be, M, N, K, O):
