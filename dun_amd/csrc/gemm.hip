@@ -246,9 +246,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     f32x4 ra[NR], rb[NR];
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile<A_KC, VEC, TB>(p.A, p.lda, m0, p.M, 0, p.K, tid, ra);
-    load_tile<B_KC, VEC, TB>(p.B, p.ldb, n0, p.N, 0, p.K, tid, rb);
+    // split-K: blockIdx.y owns [kb, ke), a whole number of K tiles (the last range may be short)
+    int kb = 0, ke = p.K;
+    if (p.ksplit > 1) {
+        const int chunk = ((p.K + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
+        kb = (int)blockIdx.y * chunk;
+        ke = kb + chunk < p.K ? kb + chunk : p.K;
+    }
+    const int nk = ke > kb ? (ke - kb + BK - 1) / BK : 0;
+    load_tile<A_KC, VEC, TB>(p.A, p.lda, m0, p.M, kb, ke, tid, ra);
+    load_tile<B_KC, VEC, TB>(p.B, p.ldb, n0, p.N, kb, ke, tid, rb);
     store_tile<A_KC, TB>(smem, tid, ra);
     store_tile<B_KC, TB>(smem + TILE, tid, rb);
     __syncthreads();
@@ -277,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
                     read_frag<B_KC, TB>(b_s, wc * WT + ni * 32 + li, t + 1, h, fb[(t + 1) & 1][ni]);
             }
             if (t == 0 && more) {
-                load_tile<A_KC, VEC, TB>(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid, ra);
-                load_tile<B_KC, VEC, TB>(p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid, rb);
+                load_tile<A_KC, VEC, TB>(p.A, p.lda, m0, p.M, kb + (kt + 1) * BK, ke, tid, ra);
+                load_tile<B_KC, VEC, TB>(p.B, p.ldb, n0, p.N, kb + (kt + 1) * BK, ke, tid, rb);
             }
             if (t == 2 && more) {
                 // Safe: every wave has passed the barrier that ended iteration kt-1, nobody reads buffer cur^1.
@@ -298,7 +305,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         __syncthreads();
     }
 
-    gemm_epilogue<false, MI>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    if (p.ksplit > 1) {
+        GemmP q = p;  // raw partial sum of this K range; splitk_sum_kernel adds the ranges in order
+        q.C = p.part + (size_t)blockIdx.y * p.M * p.N;
+        q.ldc = p.N;
+        q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr;
+        gemm_epilogue<false, MI>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    } else {
+        gemm_epilogue<false, MI>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -600,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
 // C[m][n] = part[0][m][n] + part[1][m][n] + ... (fixed order: reproducible)
 __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ part, int ksplit, int M, int N,
                                                          float* __restrict__ C, int ldc) {
-    const size_t n4 = (size_t)M * N / 4;  // N % 128 == 0
+    const size_t n4 = (size_t)M * N / 4;  // N % 4 == 0
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
         for (int k = 1; k < ksplit; ++k) v += reinterpret_cast<const f32x4*>(part + (size_t)k * M * N)[i];
@@ -631,14 +646,23 @@ static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream
         hipLaunchKernelGGL(splitk_sum_kernel, dim3(g), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
     } else if (dma)
         hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
-    else if (small && vec)
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 1>), dim3(grid), dim3(256), 0, s, p);
-    else if (small)
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, 1>), dim3(grid), dim3(256), 0, s, p);
-    else if (vec)
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 2>), dim3(grid), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, 2>), dim3(grid), dim3(256), 0, s, p);
+    else {
+        const dim3 g2(grid, p.ksplit > 1 ? p.ksplit : 1);
+        if (small && vec)
+            hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 1>), g2, dim3(256), 0, s, p);
+        else if (small)
+            hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, 1>), g2, dim3(256), 0, s, p);
+        else if (vec)
+            hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 2>), g2, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, 2>), g2, dim3(256), 0, s, p);
+        if (p.ksplit > 1) {
+            DUN_LAUNCH_CHECK();
+            const size_t n4 = (size_t)p.M * p.N / 4;
+            const int g = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3(g), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
+        }
+    }
     DUN_LAUNCH_CHECK();
     return DUN_OK;
 }
@@ -698,6 +722,17 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
         aligned16(d->C) && d->ldc % 4 == 0) {
         p.ksplit = 2;
         p.part = d->splitk_ws;
+    } else if (!dma && plain && !g_no_splitk && d->splitk_ws != nullptr && aligned16(d->splitk_ws) && aligned16(d->C) &&
+               d->ldc % 4 == 0 && d->N % 4 == 0) {
+        // register-staged kernels (ragged or small problems, e.g. dW_in = G^T x: 32 tiles, K = batch): one K range
+        // per 512 rows of K, as many as fill ~512 workgroups, at most 16
+        long long ks = d->K / 512;
+        if (ks > 512 / tiles) ks = 512 / tiles;
+        if (ks > 16) ks = 16;
+        if (ks >= 2 && d->splitk_ws_floats >= (size_t)ks * d->M * d->N) {
+            p.ksplit = (int)ks;
+            p.part = d->splitk_ws;
+        }
     }
     if (d->a_kcontig) {
         if (d->b_kcontig) return launch_gemm<true, true>(p, vec, dma, small, s);

@@ -48,23 +48,27 @@ struct Vec<1> {
 };
 
 // out_d[a][c] = sum_p partials[a][p][c] (fp64, fixed order); optional float copies per array.
-// workgroup = 64 columns x 4 partial-lanes.
+// workgroup = 16 columns x 16 partial-lanes: W/16 workgroups (the partials are L2/Infinity-Cache resident, what
+// matters is enough workgroups and a short serial loop: P/16 steps)
+constexpr int RCX = 16, RCY = 16;
 template <typename PT>
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const PT* __restrict__ partials, int P, int W,
                                                           double* __restrict__ out_d, float* __restrict__ out_f0,
                                                           float* __restrict__ out_f1) {
-    __shared__ double red[RY][CX];
-    const int tx = threadIdx.x & (CX - 1), ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * CX + tx, a = blockIdx.y;
+    __shared__ double red[RCY][RCX];
+    const int tx = threadIdx.x & (RCX - 1), ty = threadIdx.x / RCX;
+    const int c = blockIdx.x * RCX + tx, a = blockIdx.y;
     double s = 0.0;
     if (c < W) {
         const PT* src = partials + (size_t)a * P * W + c;
-        for (int p = ty; p < P; p += RY) s += (double)src[(size_t)p * W];
+        for (int p = ty; p < P; p += RCY) s += (double)src[(size_t)p * W];
     }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < W) {
-        const double t = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < RCY; ++i) t += red[i][tx];
         if (out_d) out_d[(size_t)a * W + c] = t;
         float* of = a == 0 ? out_f0 : out_f1;
         if (of) of[c] = (float)t;
@@ -362,7 +366,7 @@ static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s) {
     int rc = gemm_f32(&g, s);
     if (rc) return rc;
     if (c->train) {
-        hipLaunchKernelGGL(reduce_cols_kernel<double>, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, stats, P, W,
+        hipLaunchKernelGGL(reduce_cols_kernel<double>, dim3(ceil_div(W, RCX), 2), dim3(256), 0, s, stats, P, W,
                            c->bn_sums, (float*)nullptr, (float*)nullptr);
         DUN_LAUNCH_CHECK();
     }
@@ -449,7 +453,7 @@ static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
                            P, slab_rows_for(B), c->ws);
     DUN_LAUNCH_CHECK();
     // local sums are this rank's dbeta / dgamma; the fp64 copy is what a sharded job all-reduces
-    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 2), dim3(256), 0, s, c->ws, P, W, c->bn_sums,
+    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, RCX), 2), dim3(256), 0, s, c->ws, P, W, c->bn_sums,
                        c->g.beta + (size_t)i * W, c->g.gamma + (size_t)i * W);
     DUN_LAUNCH_CHECK();
     return DUN_OK;
@@ -468,7 +472,7 @@ static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipS
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, Z, mean, rstd, gamma,
                            c->bn_sums, global_batch, B, W, slab_rows_for(B), c->dU, c->ws);
     DUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W,
+    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, RCX), 1), dim3(256), 0, s, c->ws, P, W,
                        (double*)nullptr, c->g.b + (size_t)i * W, (float*)nullptr);
     DUN_LAUNCH_CHECK();
     // dW_i[n_out, k_in] = sum_b dU[b, n_out] * H_i[b, k_in]
@@ -501,6 +505,7 @@ static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
     g.B = c->x; g.ldb = c->din; g.b_kcontig = 0;
     g.C = c->g.w_in; g.ldc = c->din;
     g.M = W; g.N = c->din; g.K = B;
+    g.splitk_ws = c->ws; g.splitk_ws_floats = c->ws_floats;  // ws is free here; colsum below reuses it afterwards
     int rc = gemm_f32(&g, s);
     if (rc) return rc;
     if (vec4_ok(W, c->G))
@@ -508,7 +513,7 @@ static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
     else
         hipLaunchKernelGGL(colsum_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, B, W, slab_rows_for(B), c->ws);
     DUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, CX), 1), dim3(256), 0, s, c->ws, P, W,
+    hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, RCX), 1), dim3(256), 0, s, c->ws, P, W,
                        (double*)nullptr, c->g.b_in, (float*)nullptr);
     DUN_LAUNCH_CHECK();
     return DUN_OK;

@@ -55,7 +55,9 @@ def test_gemm_layouts(be, M, N, K, a_kc, b_kc):
 
 @pytest.mark.parametrize("a_kc", [True, False])
 @pytest.mark.parametrize("b_kc", [True, False])
-@pytest.mark.parametrize("M,N,K", [(2048, 1024, 4096), (2048, 2048, 2048)])
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 4096), (2048, 2048, 2048),
+                                   # register-staged kernels: the input-layer dW shape, a ragged one, a short last range
+                                   (2048, 64, 8192), (300, 100, 5000), (128, 12, 1100)])
 def test_gemm_split_k(be, M, N, K, a_kc, b_kc):
     """Few tiles + long K + a workspace: two K ranges per tile, summed in a fixed order (the dW = dU^T H shape)."""
     g = torch.Generator().manual_seed(M + N + K)
@@ -63,7 +65,7 @@ def test_gemm_split_k(be, M, N, K, a_kc, b_kc):
     B = torch.randn(K, N, generator=g)
     A_st = dev(A if a_kc else A.t().contiguous())
     B_st = dev(B.t().contiguous() if b_kc else B)
-    ws = torch.empty(2 * M * N, device="cuda")
+    ws = torch.empty(16 * M * N, device="cuda")
     C1 = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc, splitk_ws=ws)
     C2 = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc, splitk_ws=ws)
     C0 = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc)
