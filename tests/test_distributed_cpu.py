@@ -134,3 +134,50 @@ def test_per_replica_batchnorm_differs():
     # per-replica statistics are a different (DataParallel-like) computation: close, but not the same numbers
     assert abs(r0[0][0][0] - rets[0][0]) > 1e-6 * abs(rets[0][0])
     assert np.abs(r0[2]["rm"] - st["rm"]).max() > 0
+
+
+def _img_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dun_amd import kernels
+        from dun_amd.distributed import shard
+        from tests.cpu_backend import CpuBackend
+        from tests.test_image_dun import build
+        kernels.set_backend(CpuBackend())
+        c = Case("img_r18")
+        net, meta = build(c, cuda=False)
+        if rank == 1:
+            with torch.no_grad():
+                for p in net.model.parameters():
+                    p.add_(0.1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            shard(net)
+        x, y = c.t("x"), c.t("y").long()
+        B = x.shape[0] // world
+        xs, ys = x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B]
+        # this rank's own gradient of the global-batch loss, before the exchange
+        net.model.train()
+        act = net.model.forward(xs)
+        prior = net.model.get_w_prior_loglike()
+        out = net.prob_model.fused_objective(prior, act, ys, net.f_neg_loglike, meta["N"])
+        local = torch.autograd.grad(act, net.model.output_block.weight, out.dact.view_as(act), retain_graph=False)[0]
+        rets = [net.fit(xs, ys) for _ in range(2)]
+        flat = torch.cat([p.data.reshape(-1) for p in net.model.parameters()])
+        ret[rank] = (rets, flat.numpy(), net.prob_model.q_logits.data.numpy().copy(), local.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_image_dun_two_ranks_stay_identical():
+    """Image DUN (conv trunk in torch, per-replica BatchNorm2d): loose-parameter gradients are SUM all-reduced."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_img_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert np.allclose(r0[0], r1[0], rtol=1e-6)              # both ranks report the global-batch objective / metrics
+    assert np.array_equal(r0[1], r1[1]) and np.array_equal(r0[2], r1[2])   # replicas identical after two steps
+    assert np.all(np.isfinite(r0[1]))
+    assert not np.allclose(r0[3], r1[3])                     # (the ranks did see different rows)
