@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0)
+    ap.add_argument("--channels-last", action="store_true",
+                    help="image workloads: NHWC conv trunk; the head/ELBO path is unaffected (measured SLOWER with MIOpen's "
+                         "immediate mode on fp32: 13.0 s vs 2.85 s per c5_cifar step -- off by default)")
     args = ap.parse_args()
 
     image = args.workload in IMAGE_WORKLOADS
@@ -274,6 +277,9 @@ def main():
         net = build_image_net(channels, N_train)
         g = torch.Generator().manual_seed(rank)
         x = torch.randn(B_local, channels, side, side, generator=g).cuda()
+        if args.channels_last:
+            net.model.to(memory_format=torch.channels_last)
+            x = x.contiguous(memory_format=torch.channels_last)
         y = torch.randint(0, 10, (B_local,), generator=g).cuda()
     else:
         net = build_net(din, W, L, N_train, lr, momentum, wd)

@@ -11,6 +11,25 @@ import torch
 from . import kernels
 
 
+def _dense_views(p, g, st):
+    """(param, grad, momentum) as contiguous tensors over the SAME element order.  Contiguous parameters pass through;
+    channels_last (NHWC) conv weights are stepped in their own memory order (an elementwise update does not care)."""
+    if p.is_contiguous():
+        if "momentum_buffer" not in st:
+            st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return p, (g if g.is_contiguous() else g.contiguous()), st["momentum_buffer"]
+    if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last):
+        if "momentum_buffer" not in st or st["momentum_buffer"].stride() != p.stride():
+            old = st.get("momentum_buffer")
+            st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.channels_last)
+            if old is not None:
+                st["momentum_buffer"].copy_(old)
+        if g.stride() != p.stride():
+            g = g.contiguous(memory_format=torch.channels_last)
+        return tuple(t.permute(0, 2, 3, 1) for t in (p, g, st["momentum_buffer"]))
+    raise RuntimeError("FusedSGD: parameter with strides %s is neither contiguous nor channels_last" % (p.stride(),))
+
+
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-2, momentum=0.0, weight_decay=0.0):
         defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay)
@@ -44,11 +63,8 @@ class FusedSGD(torch.optim.Optimizer):
                     continue
                 if p.grad is None:
                     continue
-                st = self.state[p]
-                if "momentum_buffer" not in st:
-                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                be.sgd_step(p.data, g, st["momentum_buffer"], lr, mom, wd)
+                pv, gv, bv = _dense_views(p.data, p.grad, self.state[p])
+                be.sgd_step(pv, gv, bv, lr, mom, wd)
             for owner in owners:
                 st = self.state[owner._param_list[0]]
                 buf = st.get("flat_momentum_buffer")

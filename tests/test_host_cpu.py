@@ -221,3 +221,22 @@ def test_device_loader_batches_and_rank_shards():
     assert len(parts[0]) == len(parts[1]) == len(full) == 3
     for b0, b1, bf in zip(parts[0], parts[1], full):
         assert torch.equal(torch.cat([b0[1], b1[1]]), bf[1])
+
+
+def test_fused_sgd_steps_channels_last_parameters(cpu_backend):
+    """A conv weight in NHWC memory order is stepped in place, in its own element order, like torch.optim.SGD does."""
+    from dun_amd.optim import FusedSGD
+    g = torch.Generator().manual_seed(0)
+    w0 = torch.randn(8, 4, 3, 3, generator=g)
+    grads = [torch.randn(8, 4, 3, 3, generator=g) for _ in range(3)]
+    ref = torch.nn.Parameter(w0.clone())
+    mine = torch.nn.Parameter(w0.clone().contiguous(memory_format=torch.channels_last))
+    o_ref = torch.optim.SGD([ref], lr=0.1, momentum=0.9, weight_decay=1e-2)
+    o_mine = FusedSGD([mine], lr=0.1, momentum=0.9, weight_decay=1e-2)
+    for i, gr in enumerate(grads):
+        ref.grad = gr.clone()
+        mine.grad = gr.clone() if i == 1 else gr.clone().contiguous(memory_format=torch.channels_last)
+        o_ref.step()
+        o_mine.step()
+    assert mine.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(mine.data, ref.data, rtol=1e-6, atol=1e-7)
