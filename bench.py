@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0)
+    ap.add_argument("--miopen-benchmark", action="store_true",
+                    help="image workloads: let MIOpen search per conv shape (torch.backends.cudnn.benchmark, as the "
+                         "reference's wrapper sets it) instead of immediate mode; minutes of extra warm-up on a cold box")
     ap.add_argument("--channels-last", action="store_true",
                     help="image workloads: NHWC conv trunk; the head/ELBO path is unaffected (measured SLOWER with MIOpen's "
                          "immediate mode on fp32: 13.0 s vs 2.85 s per c5_cifar step -- off by default)")
@@ -275,6 +278,7 @@ def main():
 
     if image:
         net = build_image_net(channels, N_train)
+        torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
         g = torch.Generator().manual_seed(rank)
         x = torch.randn(B_local, channels, side, side, generator=g).cuda()
         if args.channels_last:
