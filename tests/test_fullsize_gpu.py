@@ -144,3 +144,32 @@ def test_likelihood_sums_add_over_batch_shards():
         parts = s if parts is None else parts + s
     # fp32 only inside a thread's <= 16 elements, fp64 from there on: regrouping moves the sums by ~1e-8 relative
     assert rel(parts, full) < 1e-6
+
+
+def test_full_size_image_head_and_softmax_elbo_against_fp64_on_device():
+    """C5 geometry of the custom-kernel part of an image DUN: 12 exits x 4096 rows x 2048 pooled features, 10 classes.
+    Batched head + fused CE/ELBO + head backward against the oracle's functions in fp64 on the same device tensors."""
+    from dun_amd import kernels
+    be = kernels.backend()
+    D, B, K, C, N = 12, 4096, 2048, 10, 50000.0
+    g = torch.Generator(device="cuda").manual_seed(5)
+    feat = torch.randn(D, B, K, device="cuda", generator=g).relu_()
+    w = torch.randn(C, K, device="cuda", generator=g) * 0.03
+    b = torch.randn(C, device="cuda", generator=g) * 0.1
+    y = torch.randint(0, C, (B,), device="cuda", generator=g)
+    ql = 0.3 * torch.randn(D, device="cuda", generator=g)
+    logprior = torch.full((D,), 1.0 / D, device="cuda").log()
+    act = be.head_forward(feat.view(D * B, K), w, b).view(D, B, C)
+    sums, dact, _ = be.ll_pass(act, y, False, None, ql, True, 1.0 / B, want_dact=True)
+    res = be.depth_finalize(sums, False, ql, logprior, None, None, N, B, 1.0, 1e-35, 0)
+    dw, db, dfeat = be.head_backward(feat.view(D * B, K), w, dact.view(D * B, C), need_dH=True)
+    # fp64 truth
+    f64, w64, b64 = feat.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    a64 = torch.nn.functional.linear(f64, w64, b64)
+    z = torch.zeros(D, device="cuda", dtype=torch.float64)
+    joint = O.joint_loglike(z, a64, y, False, N)
+    elbo = O.elbo(z, a64, y, False, N, ql.double(), logprior.double())
+    gw, gb, gf = torch.autograd.grad(-elbo / N, [w64, b64, f64])
+    assert rel(act, a64.detach()) < 1e-5
+    assert rel(res[8:8 + D], joint.detach()) < 1e-5 and rel(res[0], elbo.detach()) < 1e-5
+    assert rel(dw, gw) < 2e-5 and rel(db, gb) < 2e-5 and rel(dfeat.view(D, B, K), gf) < 2e-5
