@@ -245,6 +245,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0)
+    ap.add_argument("--predict", action="store_true",
+                    help="time DUN_VI.predict(x, get_std=True) (eval-mode forward + depth-marginal predictor) instead "
+                         "of fit; prints the same JSON line with metric 'DUN predict samples/sec'")
     ap.add_argument("--miopen-benchmark", action="store_true",
                     help="image workloads: let MIOpen search per conv shape (torch.backends.cudnn.benchmark, as the "
                          "reference's wrapper sets it) instead of immediate mode; minutes of extra warm-up on a cold box")
@@ -297,6 +300,36 @@ def main():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.predict:
+        step = (lambda: net.predict(x, get_std=True)) if not image else (lambda: net.predict(x))
+        net.fit(x, y)  # one training step so that the BatchNorm running statistics and q are not the initial ones
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        first = out[0] if isinstance(out, tuple) else out
+        if not bool(torch.isfinite(first).all()):
+            raise SystemExit("bench.py: non-finite predictions")
+        if rank == 0:
+            print(json.dumps({
+                "metric": "DUN predict samples/sec", "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s: predict, global batch %d (%d rows/GPU)" % (args.workload, B, B_local),
+                           "parallelism": "dp%d batch-sharded (no collective: eval-mode BatchNorm)" % world}}), flush=True)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     last = None
     for i in range(args.warmup):
