@@ -8,6 +8,9 @@ is exchanged explicitly, and nothing else is:
   * the per-depth likelihood sums: one fp64 [D] all-reduce per step (the VI backward does not wait for it);
   * parameter gradients: SUM all-reduce (the loss already carries 1/global_batch), issued per block while the
     backward of the shallower blocks is still running, so the 16 MB-per-block messages overlap with the GEMMs.
+The gradient messages travel on a SECOND communicator over the same ranks: collectives of one communicator execute in
+issue order on one stream, and the 16 KB BatchNorm exchange of block i-1 -- which the compute stream waits for --
+must not queue behind the 16 MB gradient message of block i that was issued just before it.
 All ranks must hold the same number of rows (global batch = local batch * world size).
 """
 import torch
@@ -24,6 +27,11 @@ class Shard(object):
         self.sync_bn = sync_bn
         self.overlap = overlap
         self._pending = []
+        # bulk (gradient) traffic gets its own communicator / stream; every rank creates it, in the same order
+        self.grad_group = group
+        if self.world > 1 and overlap:
+            ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+            self.grad_group = dist.new_group(ranks=ranks)
 
     def global_batch(self, local_batch):
         return local_batch * self.world
@@ -45,9 +53,9 @@ class Shard(object):
             pieces = [p for p in (flat[:lo], flat[hi:]) if p.numel()]
         for p in pieces:
             if self.overlap:
-                self._pending.append(dist.all_reduce(p, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._pending.append(dist.all_reduce(p, op=dist.ReduceOp.SUM, group=self.grad_group, async_op=True))
             else:
-                dist.all_reduce(p, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(p, op=dist.ReduceOp.SUM, group=self.grad_group)
 
     def wait_gradients(self):
         for h in self._pending:
