@@ -724,12 +724,15 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
         p.part = d->splitk_ws;
     } else if (!dma && plain && !g_no_splitk && d->splitk_ws != nullptr && aligned16(d->splitk_ws) && aligned16(d->C) &&
                d->ldc % 4 == 0 && d->N % 4 == 0) {
-        // register-staged kernels (ragged or small problems, e.g. dW_in = G^T x: 32 tiles, K = batch): one K range
-        // per 512 rows of K, as many as fill ~512 workgroups, at most 16
-        long long ks = d->K / 512;
+        // register-staged kernels (ragged or small problems, e.g. dW_in = G^T x: 32 tiles, K = batch; the 100-wide
+        // UCI nets: 4 tiles, K = 512): one K range per 128 rows of K, as many as fill ~512 workgroups and fit the
+        // workspace, at most 16
+        long long ks = d->K / 128;
         if (ks > 512 / tiles) ks = 512 / tiles;
         if (ks > 16) ks = 16;
-        if (ks >= 2 && d->splitk_ws_floats >= (size_t)ks * d->M * d->N) {
+        const long long fit = (long long)(d->splitk_ws_floats / ((size_t)d->M * d->N));
+        if (ks > fit) ks = fit;
+        if (ks >= 2) {
             p.ksplit = (int)ks;
             p.part = d->splitk_ws;
         }

@@ -528,7 +528,7 @@ extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
     const size_t P = (size_t)ceil_div(B, 64);  // upper bound of the GEMM's row tiles (and of num_slabs(B))
     const size_t cols = 4 * P * (size_t)W;  // fp64 [2][P][W] forward statistics partials
     const size_t hb = head_backward_ws((L + 1) * B, W, O);
-    const size_t sk = L > 0 ? 2 * (size_t)W * W : 0;  // split-K partials of dW = dU^T H
+    const size_t sk = L > 0 ? 4 * (size_t)W * W : 0;  // split-K partials of dW = dU^T H (2 ranges at C3, 4 on small nets)
     size_t m = cols > hb ? cols : hb;
     if (sk > m) m = sk;
     return m + 64;
