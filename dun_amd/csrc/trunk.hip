@@ -92,6 +92,49 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
 }
 
+// reduce_cols_kernel<double> over the two statistic arrays + bn_finalize_kernel in one launch (single-device forward:
+// no all-reduce point between them).  Same summation order as the two-kernel path, so both give the same bits.
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* __restrict__ partials, int P, int W,
+                                                                 double count, float eps, float momentum,
+                                                                 double* __restrict__ sums, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd,
+                                                                 float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var) {
+    __shared__ double red[2][RCY][RCX];
+    const int tx = threadIdx.x & (RCX - 1), ty = threadIdx.x / RCX;
+    const int c = blockIdx.x * RCX + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < W) {
+        const double* a1 = partials + c;
+        const double* a2 = partials + (size_t)P * W + c;
+        for (int p = ty; p < P; p += RCY) {
+            s1 += a1[(size_t)p * W];
+            s2 += a2[(size_t)p * W];
+        }
+    }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < W) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < RCY; ++i) {
+            t1 += red[0][i][tx];
+            t2 += red[1][i][tx];
+        }
+        sums[c] = t1;
+        sums[W + c] = t2;
+        const double m = t1 / count;
+        double var = t2 / count - m * m;
+        var = var > 0.0 ? var : 0.0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unbiased = var * (count / (count - 1.0));
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+}
+
 // h_out = [h_in +] gamma * (z - mean) * rstd + beta.  stat_is_var: `rstd` holds a variance (eval mode).
 template <int VW>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ Z, const float* __restrict__ Hin,
@@ -351,7 +394,7 @@ static int input_layer(const dun_fc_ctx* c, hipStream_t s) {
     return gemm_f32(&g, s);
 }
 
-static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s) {
+static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s, bool reduce_stats = true) {
     const int W = c->W, P = gemm_colstat_tiles(c->B, W);  // the GEMM's own row tiling (128, or 64 on small problems)
     dun_gemm_desc g;
     memset(&g, 0, sizeof(g));
@@ -365,7 +408,7 @@ static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s) {
     g.colstats = c->train ? stats : nullptr;
     int rc = gemm_f32(&g, s);
     if (rc) return rc;
-    if (c->train) {
+    if (c->train && reduce_stats) {
         hipLaunchKernelGGL(reduce_cols_kernel<double>, dim3(ceil_div(W, RCX), 2), dim3(256), 0, s, stats, P, W,
                            c->bn_sums, (float*)nullptr, (float*)nullptr);
         DUN_LAUNCH_CHECK();
@@ -373,7 +416,8 @@ static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s) {
     return DUN_OK;
 }
 
-static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s) {
+// from_partials: the GEMM's per-tile statistics are still unreduced in the workspace (single-device forward)
+static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s, bool from_partials = false) {
     const int W = c->W, B = c->B;
     const float* mean;
     const float* stat;
@@ -383,9 +427,15 @@ static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream
                     global_batch);
         float* m = c->bn_mean + (size_t)i * W;
         float* r = c->bn_rstd + (size_t)i * W;
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(W, 256)), dim3(256), 0, s, c->bn_sums, W, global_batch,
-                           c->bn_eps, c->bn_momentum, m, r, c->running_mean + (size_t)i * W,
-                           c->running_var + (size_t)i * W);
+        if (from_partials)
+            hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(W, RCX)), dim3(256), 0, s,
+                               reinterpret_cast<const double*>(c->ws), gemm_colstat_tiles(B, W), W, global_batch,
+                               c->bn_eps, c->bn_momentum, c->bn_sums, m, r, c->running_mean + (size_t)i * W,
+                               c->running_var + (size_t)i * W);
+        else
+            hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(W, 256)), dim3(256), 0, s, c->bn_sums, W, global_batch,
+                               c->bn_eps, c->bn_momentum, m, r, c->running_mean + (size_t)i * W,
+                               c->running_var + (size_t)i * W);
         DUN_LAUNCH_CHECK();
         mean = m; stat = r; is_var = 0;
     } else {
@@ -557,8 +607,8 @@ extern "C" int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream) {
     if (rc) return rc;
     if ((rc = input_layer(c, STREAM))) return rc;
     for (int i = 0; i < c->depth; ++i) {
-        if ((rc = block_linear(c, i, STREAM))) return rc;
-        if ((rc = block_norm(c, i, (double)c->B, STREAM))) return rc;
+        if ((rc = block_linear(c, i, STREAM, /*reduce_stats=*/false))) return rc;
+        if ((rc = block_norm(c, i, (double)c->B, STREAM, /*from_partials=*/c->train != 0))) return rc;
     }
     return head(c, STREAM);
 }
