@@ -8,9 +8,12 @@ is exchanged explicitly, and nothing else is:
   * the per-depth likelihood sums: one fp64 [D] all-reduce per step (the VI backward does not wait for it);
   * parameter gradients: SUM all-reduce (the loss already carries 1/global_batch), issued per block while the
     backward of the shallower blocks is still running, so the 16 MB-per-block messages overlap with the GEMMs.
-The gradient messages travel on a SECOND communicator over the same ranks: collectives of one communicator execute in
-issue order on one stream, and the 16 KB BatchNorm exchange of block i-1 -- which the compute stream waits for --
-must not queue behind the 16 MB gradient message of block i that was issued just before it.
+Everything travels on ONE communicator (collectives of one communicator execute in issue order on one stream; several
+communicators running concurrently are a known deadlock hazard when devices schedule their kernels in different
+orders).  The 16 KB BatchNorm exchange of block i-1 -- which the compute stream waits for -- must therefore not be
+issued behind the 16 MB gradient message of block i: the trunk backward issues the gradient message of block i only
+AFTER the BatchNorm exchange of block i-1 (see arq_uncert_fc_resnet._run_backward), when the next small message is
+a whole block of GEMMs away.
 All ranks must hold the same number of rows (global batch = local batch * world size).
 """
 import torch
@@ -27,11 +30,7 @@ class Shard(object):
         self.sync_bn = sync_bn
         self.overlap = overlap
         self._pending = []
-        # bulk (gradient) traffic gets its own communicator / stream; every rank creates it, in the same order
         self.grad_group = group
-        if self.world > 1 and overlap:
-            ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
-            self.grad_group = dist.new_group(ranks=ranks)
 
     def global_batch(self, local_batch):
         return local_batch * self.world

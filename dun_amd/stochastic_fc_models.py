@@ -219,12 +219,20 @@ class arq_uncert_fc_resnet(nn.Module):
         else:
             gb = dist.global_batch(buf.B)
             be.fc_bwd_begin(buf)
+            # The gradient message of block i is issued one stage late, right AFTER the BatchNorm exchange of block
+            # i-1: on the single communicator stream the small message the compute stream waits for is then never
+            # queued behind a 16 MB one (the next small message is a whole block of GEMMs away).
+            held = None
             for i in range(self.n_layers - 1, -1, -1):
                 be.fc_bwd_block_reduce(buf, i)
                 if dist.sync_bn:
                     dist.all_reduce(buf.bn_sums)
+                if held is not None:
+                    dist.reduce_gradient_async(held)
                 be.fc_bwd_block_apply(buf, i, gb if dist.sync_bn else buf.B)
-                dist.reduce_gradient_async(self.stacked_grad["w"][i])
+                held = self.stacked_grad["w"][i]
+            if held is not None:
+                dist.reduce_gradient_async(held)
             be.fc_bwd_end(buf)
             dist.reduce_gradient_async(self.flat_grads, exclude=self.stacked_grad["w"])
         for p, g in zip(self._param_list, self._grad_views):

@@ -1,0 +1,87 @@
+"""The batch-sharded path on the REAL kernels with two ranks: two processes share the one GPU of the test box and
+exchange through gloo (RCCL refuses two ranks on one device), each on half the rows of the global batch.  With
+synchronised BatchNorm the two-rank step must reproduce the single-process step on the full batch: objective, metrics,
+parameters, running statistics.  (The stand-in-backend version of this test runs on CPU in test_distributed_cpu.py.)"""
+import contextlib
+import io
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.util import Case
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _state(net):
+    out = {"flat": net.model.flat_params, "rm": net.model.running_mean, "rv": net.model.running_var}
+    if hasattr(net.prob_model, "q_logits"):
+        out["q"] = net.prob_model.q_logits.data
+    if net.regression:
+        out["ls"] = net.f_neg_loglike.log_std.data
+    return {k: v.detach().cpu().numpy().copy() for k, v in out.items()}
+
+
+def _worker(rank, world, port, name, steps, outdir):
+    import faulthandler
+    faulthandler.dump_traceback_later(45, exit=True)  # a stalled rank ends with its stack instead of a hung test
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dun_amd.distributed import shard
+        from tests.test_wrappers_gpu import build_net
+        c = Case(name)
+        net = build_net(c)
+        if rank == 1:  # replicas may start different: shard() must broadcast rank 0's state
+            net.model.flat_params.add_(0.25)
+        with contextlib.redirect_stdout(io.StringIO()):
+            shard(net, sync_bn=True)
+        x, y = c.t("x").cuda(), c.y().cuda()
+        B = x.shape[0] // world
+        xs, ys = x[rank * B:(rank + 1) * B].contiguous(), y[rank * B:(rank + 1) * B].contiguous()
+        rets = [net.fit(xs, ys) for _ in range(steps)]
+        ev = net.eval(xs, ys)
+        torch.cuda.synchronize()
+        torch.save((rets, ev, _state(net)), os.path.join(outdir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["c3_reduced", "cls_fc", "mll_small"])
+def test_two_ranks_on_one_gpu_match_single_process(name, tmp_path):
+    steps = 2
+    # (results travel through files: a multiprocessing.Manager would fork a server out of a process that may already
+    # hold a GPU context)
+    mp.spawn(_worker, args=(2, _free_port(), name, steps, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in (0, 1))
+    from tests.test_wrappers_gpu import build_net
+    c = Case(name)
+    net = build_net(c)
+    net.graph_steps = False
+    x, y = c.t("x").cuda(), c.y().cuda()
+    rets = [net.fit(x, y) for _ in range(steps)]
+    ev = net.eval(x, y)
+    st = _state(net)
+    for a, b, s in zip(r0[0], r1[0], rets):
+        assert np.allclose(a, b, rtol=1e-6, equal_nan=True)      # both ranks report the global-batch numbers
+        assert np.allclose(a, s, rtol=2e-5, atol=1e-6, equal_nan=True), (a, s)
+    assert np.allclose(r0[1], ev, rtol=2e-5, equal_nan=True)
+    for k in st:
+        assert np.array_equal(r0[2][k], r1[2][k]), k             # replicas stay bit-identical
+        scale = np.abs(st[k]).max()
+        assert np.abs(r0[2][k] - st[k]).max() <= 2e-5 * scale + 1e-7, k
