@@ -5,7 +5,9 @@ parameters, running statistics.  (The stand-in-backend version of this test runs
 
 NOT collected by pytest (file name): gloo all-reduces on device tensors stall intermittently when two ranks share one
 GPU on the test box (both ranks sit inside the same dist.all_reduce call; seen with the classification case, never with
-c3_reduced), and a stalled rank would take the whole GPU tier down.  Run by hand:
+c3_reduced; scripts/debug_dist_gpu.py shows one rank's compute stream still waiting -- on gloo's copy-back stream --
+while the other rank's is idle, and no stall at all once every backend call is followed by a device synchronise, i.e.
+the kernels themselves complete), and a stalled rank would take the whole GPU tier down.  Run by hand:
     python -m pytest tests/manual_two_ranks_one_gpu.py -q -k c3_reduced
 Result on the round-1 box: c3_reduced passes (objective / metrics / parameters of the two-rank run equal the
 single-process run to 2e-5, replicas bit-identical)."""
