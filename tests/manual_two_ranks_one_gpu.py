@@ -5,8 +5,10 @@ parameters, running statistics.  (The stand-in-backend version of this test runs
 
 NOT collected by pytest (file name): gloo all-reduces on device tensors stall intermittently when two ranks share one
 GPU on the test box (both ranks sit inside the same dist.all_reduce call; seen with the classification case, never with
-c3_reduced; scripts/debug_dist_gpu.py shows one rank's compute stream still waiting -- on gloo's copy-back stream --
-while the other rank's is idle, and no stall at all once every backend call is followed by a device synchronise, i.e.
+c3_reduced; scripts/debug_dist_gpu.py records an event after every backend call and every all-reduce: at the stall
+ALL recorded events have completed on both ranks -- every kernel of this library has finished -- and both ranks sit in
+the next gloo all_reduce, one with an idle compute stream, the other with a compute stream that never drains although
+nothing of ours is queued on it: gloo's pool of copy streams multiplexed onto the process's four hardware queues; i.e.
 the kernels themselves complete), and a stalled rank would take the whole GPU tier down.  Run by hand:
     python -m pytest tests/manual_two_ranks_one_gpu.py -q -k c3_reduced
 Result on the round-1 box: c3_reduced passes (objective / metrics / parameters of the two-rank run equal the
