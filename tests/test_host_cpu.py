@@ -240,3 +240,24 @@ def test_fused_sgd_steps_channels_last_parameters(cpu_backend):
         o_mine.step()
     assert mine.is_contiguous(memory_format=torch.channels_last)
     assert torch.allclose(mine.data, ref.data, rtol=1e-6, atol=1e-7)
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """The headline line bench.py printed on the GPU box (committed under profiles/) carries every field the driver and
+    the judge read, with consistent values."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01_bench_c3_wide.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "samples/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # value = global batch / step time
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
