@@ -308,6 +308,91 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
     if (tid == 0) partials[(size_t)d * nparts + part] = tot;
 }
 
+// 32 < C <= 1024 (CIFAR-100 / ImageNet-sized heads): the same LDS staging with G lanes per row (C/G <= 32 logits per
+// lane in registers, log2 G shuffle levels per reduction instead of six), `tile_rows` rows per pass (<= 32 KiB).
+template <int G, int KMAX>
+__global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* __restrict__ act,
+                                                                  const int64_t* __restrict__ y,
+                                                                  const float* __restrict__ w, int w_is_logits, int D,
+                                                                  int B, int C, float inv_batch,
+                                                                  float* __restrict__ dact, float* __restrict__ ll,
+                                                                  double* __restrict__ partials, int nparts,
+                                                                  int tile_rows) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    __shared__ double red[4];
+    __shared__ float sh_w;
+    const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const int gl = tid % G, grp = tid / G;
+    constexpr int NGROUPS = 256 / G;
+    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
+    const float coef = wd * inv_batch;
+    const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
+    float acc = 0.f;
+    for (int r0 = part * ROWS_PER_BLOCK; r0 < row_end; r0 += tile_rows) {
+        const int nrows = min(tile_rows, row_end - r0);
+        const int nfl = nrows * C;
+        const size_t off = ((size_t)d * B + r0) * C;  // multiple of 4 floats: r0 % 4 == 0 and B*C % 4 == 0
+        const float* src = act + off;
+        for (int i = tid * 4; i < nfl; i += 1024) {
+            if (i + 3 < nfl) {
+                *reinterpret_cast<f32x4*>(tile + i) = *reinterpret_cast<const f32x4*>(src + i);
+            } else {
+                for (int e = i; e < nfl; ++e) tile[e] = src[e];
+            }
+        }
+        __syncthreads();
+        for (int row = grp; row < nrows; row += NGROUPS) {  // (uniform per group: the shuffles below stay converged)
+            float* a = tile + row * C;
+            float v[KMAX];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int j = gl + k * G;
+                v[k] = j < C ? a[j] : -INFINITY;
+                mx = fmaxf(mx, v[k]);
+            }
+            mx = group_max<G>(mx);
+            const int yb = (int)y[r0 + row];
+            float s = 0.f, ay = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                ay = (gl + k * G == yb) ? v[k] : ay;
+                v[k] = expf(v[k] - mx);  // exp(-inf) = 0 for the padding
+                s += v[k];
+            }
+            s = group_sum<G>(s);
+            ay = group_sum<G>(ay);
+            const float row_ll = ay - (mx + logf(s));
+            if (gl == 0) {
+                acc += row_ll;
+                if (ll) ll[(size_t)d * B + r0 + row] = row_ll;
+            }
+            if (dact) {
+                const float inv_s = 1.f / s;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int j = gl + k * G;
+                    if (j < C) a[j] = -coef * ((j == yb ? 1.f : 0.f) - v[k] * inv_s);
+                }
+            }
+        }
+        __syncthreads();
+        if (dact) {
+            float* dst = dact + off;
+            for (int i = tid * 4; i < nfl; i += 1024) {
+                if (i + 3 < nfl) {
+                    *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(tile + i);
+                } else {
+                    for (int e = i; e < nfl; ++e) dst[e] = tile[e];
+                }
+            }
+            __syncthreads();  // the next pass overwrites the tile
+        }
+    }
+    const double tot = block_sum<256, double>((double)acc, red);
+    if (tid == 0) partials[(size_t)d * nparts + part] = tot;
+}
+
 // out[j] = sum_i in[j*n + i], fixed order; one wavefront per output
 __global__ __launch_bounds__(64) void reduce_rows_f64_kernel(const double* __restrict__ in, int n,
                                                              double* __restrict__ out) {
@@ -684,6 +769,28 @@ extern "C" int dun_ll_softmax(const float* act, const int64_t* y, const float* w
         else
             hipLaunchKernelGGL((ll_softmax_rowthread_kernel<32>), dim3(nparts, D), dim3(256), lds, s, act, y, w,
                                w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts);
+    } else if (lds_ok) {
+        // G lanes per row with at most 32 logits per lane; rows per pass: <= 32 KiB, a multiple of 4 (16-byte aligned
+        // passes) and of the rows one sweep of the lane groups covers
+        int g = 2;
+        while (g * 32 < C) g <<= 1;
+        const int ngroups = 256 / g;
+        const int quantum = ngroups > 4 ? ngroups : 4;
+        int tile_rows = 8192 / C / quantum * quantum;
+        if (tile_rows < quantum) tile_rows = quantum;
+        if (tile_rows > ROWS_PER_BLOCK) tile_rows = ROWS_PER_BLOCK;
+        const size_t lds = (size_t)tile_rows * C * sizeof(float);
+#define DUN_RG(GG)                                                                                                  \
+    hipLaunchKernelGGL((ll_softmax_rowgroup_kernel<GG, 32>), dim3(nparts, D), dim3(256), lds, s, act, y, w, w_is_logits, \
+                       D, B, C, inv_batch, dact, ll, partials, nparts, tile_rows)
+        switch (g) {
+            case 2: DUN_RG(2); break;
+            case 4: DUN_RG(4); break;
+            case 8: DUN_RG(8); break;
+            case 16: DUN_RG(16); break;
+            default: DUN_RG(32); break;
+        }
+#undef DUN_RG
     } else {
         DUN_SOFTMAX_DISPATCH(ll_softmax_kernel, G, km, dim3(nparts, D), s, act, y, w, w_is_logits, D, B, C, inv_batch,
                              dact, ll, partials, nparts);

@@ -176,7 +176,11 @@ def test_elbo_softmax_edges(be, C):
 # thread-per-row kernel (C <= 10 / 16 / 32, B*C % 4 == 0), its ragged last chunk, and the lane-group fallbacks
 # (B*C % 4 != 0, C > 32)
 @pytest.mark.parametrize("D,B,C", [(12, 4096, 10), (3, 1000, 10), (4, 258, 2), (5, 777, 10), (2, 300, 12), (3, 516, 17),
-                                    (2, 64, 32), (2, 300, 33), (12, 70000, 10), (1, 1, 10), (2, 3, 4)])
+                                    (2, 64, 32), (2, 300, 33), (12, 70000, 10), (1, 1, 10), (2, 3, 4),
+                                    # 32 < C <= 1024: G lanes per row out of LDS (2, 4, 8, 16, 32), several passes per
+                                    # workgroup, ragged last pass; and the unaligned fallback
+                                    (3, 1000, 64), (3, 516, 100), (2, 300, 200), (2, 260, 500), (2, 70, 1000),
+                                    (2, 51, 101)])
 def test_elbo_softmax_sizes(be, D, B, C):
     g = torch.Generator().manual_seed(D * 100003 + B * 7 + C)
     act = 3.0 * torch.randn(D, B, C, generator=g)
