@@ -162,12 +162,15 @@ def kernel_rooflines(net, B_local, reps):
                            ms=ms, tflops=flops / ms / 1e9)
     u1 = torch.randn(B_local, 1, device=Z0.device) * 1e-3
     v1 = model.stacked["w_out"]
-    ms = timed(lambda: be.gemm(Z0, w0, B_local, W, W, a_kcontig=True, b_kcontig=False, R=scratch, U=u1, V=v1,
+    # dX on the operands the step left behind: A = dU of the last block processed, running gradient updated in place
+    scratch.copy_(buf.G)
+    ms = timed(lambda: be.gemm(buf.dU, w0, B_local, W, W, a_kcontig=True, b_kcontig=False, R=scratch, U=u1, V=v1,
                                out=scratch), reps)
     out["gemm_dx"] = dict(kernel="gemm_f32_dma4_kernel<A_KC=1,B_KC=0> (dX = dU W + g + dact w_out, in place)", ms=ms, tflops=flops / ms / 1e9)
     gw = model.stacked_grad["w"][0]
     skws = torch.empty(2 * W * W, device=Z0.device)
-    ms = timed(lambda: be.gemm(Z0, H0, W, W, B_local, a_kcontig=False, b_kcontig=False, out=gw, splitk_ws=skws), reps)
+    ms = timed(lambda: be.gemm(buf.dU, H0, W, W, B_local, a_kcontig=False, b_kcontig=False, out=gw, splitk_ws=skws),
+               reps)
     out["gemm_dw"] = dict(kernel="gemm_f32_dma4_kernel<A_KC=0,B_KC=0>, split-K 2 + splitk_sum (dW = dU^T H)", ms=ms, tflops=flops / ms / 1e9)
     # head over all D*B hidden rows (O=1): reads 4*D*B*W bytes once
     Hall = buf.H.view(D * B_local, W)
