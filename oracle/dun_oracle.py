@@ -294,13 +294,14 @@ class OracleNet(object):
     def __init__(self, params, prior_probs, N_train, lr=1e-2, momentum=0.5, weight_decay=0.0,
                  regression=True, vi=True, residual=True, pred_sig=None, train_q=True):
         self.p = params
-        dt = params["w_in"].dtype
-        self.prior_probs = torch.as_tensor(prior_probs, dtype=dt)
+        dt, dev = params["w_in"].dtype, params["w_in"].device  # (state lives where the parameters live)
+        self.prior_probs = torch.as_tensor(prior_probs, dtype=dt, device=dev)
         self.logprior = self.prior_probs.log()
         self.D = self.prior_probs.shape[0]
-        self.q_logits = torch.zeros(self.D, dtype=dt)
+        self.q_logits = torch.zeros(self.D, dtype=dt, device=dev)
         O = params["w_out"].shape[0]
-        self.log_std = torch.zeros(O, dtype=dt) if pred_sig is None else torch.ones(O, dtype=dt) * math.log(pred_sig)
+        self.log_std = (torch.zeros(O, dtype=dt, device=dev) if pred_sig is None
+                        else torch.ones(O, dtype=dt, device=dev) * math.log(pred_sig))
         self.train_log_std = regression and pred_sig is None
         self.train_q = train_q and vi
         self.N = N_train
@@ -320,7 +321,7 @@ class OracleNet(object):
     def objective(self, x, y, train=True):
         """(objective, joint[D], act_vec) with autograd enabled on whatever leaves require grad."""
         act_vec = fc_forward(self.p, x, train=train, residual=self.residual)
-        prior = torch.zeros(self.D, dtype=act_vec.dtype)
+        prior = torch.zeros(self.D, dtype=act_vec.dtype, device=act_vec.device)
         joint = joint_loglike(prior, act_vec, y, self.regression, self.N, self.log_std)
         if self.vi:
             e_ll = (q_probs(self.q_logits) * joint).sum()
@@ -371,7 +372,7 @@ class OracleNet(object):
 
     def exact_d_posterior(self, batches, train_bn=False):
         with torch.no_grad():
-            prior = torch.zeros(self.D, dtype=self.p["w_in"].dtype)
+            prior = torch.zeros(self.D, dtype=self.p["w_in"].dtype, device=self.p["w_in"].device)
             cum = 0
             for x, y in batches:
                 act_vec = fc_forward(self.p, x, train=train_bn, residual=self.residual)
@@ -382,7 +383,7 @@ class OracleNet(object):
 
     def exact_elbo(self, batches, train_bn=False):
         with torch.no_grad():
-            prior = torch.zeros(self.D, dtype=self.p["w_in"].dtype)
+            prior = torch.zeros(self.D, dtype=self.p["w_in"].dtype, device=self.p["w_in"].device)
             cum = 0.0
             for x, y in batches:
                 act_vec = fc_forward(self.p, x, train=train_bn, residual=self.residual)

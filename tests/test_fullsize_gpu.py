@@ -173,3 +173,32 @@ def test_full_size_image_head_and_softmax_elbo_against_fp64_on_device():
     assert rel(act, a64.detach()) < 1e-5
     assert rel(res[8:8 + D], joint.detach()) < 1e-5 and rel(res[0], elbo.detach()) < 1e-5
     assert rel(dw, gw) < 2e-5 and rel(db, gb) < 2e-5 and rel(dfeat.view(D, B, K), gf) < 2e-5
+
+
+def test_full_batch_training_trajectory_against_the_oracle_on_device():
+    """Three DUN_VI.fit steps at width 2048 / batch 65536 (6 blocks): returned (ELBO estimate, NLL, RMSE) triples, the
+    parameters after the steps, q and log_std, against OracleNet running the same steps through torch's fp32 kernels."""
+    L, B = 6, 65536
+    net = build(L)
+    x, y = data(B)
+    p = {k: net.model.stacked[k].detach().clone() for k in O.PARAM_KEYS}
+    p0 = {k: v.clone() for k, v in p.items()}
+    p["running_mean"] = torch.zeros(L, W, device="cuda")
+    p["running_var"] = torch.ones(L, W, device="cuda")
+    p["num_batches_tracked"] = torch.zeros(L, dtype=torch.int64, device="cuda")
+    D = L + 1
+    onet = O.OracleNet(p, [1.0 / D] * D, N_TRAIN, lr=1e-4, momentum=0.5, weight_decay=0.0, regression=True, vi=True)
+    onet.q_logits = net.prob_model.q_logits.detach().clone()
+    onet.log_std = net.f_neg_loglike.log_std.detach().clone()
+    for step in range(3):
+        got = net.fit(x, y)
+        want = onet.fit(x, y)
+        assert all(abs(g - w) <= 2e-5 * abs(w) + 1e-7 for g, w in zip(got, want)), (step, got, want)
+    for k in O.PARAM_KEYS:
+        # the UPDATE (three accumulated fp32 gradients) to gradient accuracy, the parameter itself to fp32 accuracy
+        assert rel2(net.model.stacked[k].detach() - p0[k], onet.p[k] - p0[k]) < 3e-3, k
+        assert float((net.model.stacked[k].detach() - onet.p[k]).abs().max()) < 1e-5 * float(p0[k].abs().max() + 1), k
+    assert rel(net.model.running_mean, onet.p["running_mean"]) < 1e-5
+    assert rel(net.model.running_var, onet.p["running_var"]) < 1e-5
+    assert rel(net.prob_model.q_logits.detach(), onet.q_logits) < 1e-4
+    assert rel(net.f_neg_loglike.log_std.detach(), onet.log_std) < 1e-4
