@@ -1,9 +1,11 @@
-"""Epoch loop for FC DUNs with the reference's signature and return tuple (src/DUN/train_fc.py:12-148).
+"""Epoch loop for FC DUNs: same call signature, side effects and return tuple as the reference's ``train_fc_DUN``
+(src/DUN/train_fc.py:12-148), organised around a small per-run record instead of a dozen parallel arrays.
 
-Per epoch: ``net.fit`` over the train loader with batch-size-weighted accumulation of (objective, NLL, err),
-optional exact-posterior / exact-ELBO tracking, a dev pass every ``nb_its_dev`` epochs, `theta_last.dat` /
-`theta_best.dat` checkpoints, early stopping on the running objective, and the q warm-up used by the scripts
-(``q_nograd_its`` epochs with ``q_logits`` frozen).
+What an epoch does, in order: q warm-up switch (``q_nograd_its`` epochs with ``q_logits`` frozen) -> one pass of
+``net.fit`` over the train loader (batch-size-weighted means of objective / NLL / error) -> ``net.update_lr()`` ->
+optional exact depth posterior and exact ELBO over the whole train set -> a dev pass every ``nb_its_dev`` epochs ->
+``theta_last.dat`` every ``save_freq`` epochs, ``theta_best.dat`` when the running objective improves on an even epoch
+-> early stop when it has not improved for ``early_stop`` epochs.
 """
 import os
 import tempfile
@@ -15,16 +17,37 @@ import torch
 from .utils import cprint, mkdir
 
 
-def _weighted_pass(loader, step, flat_ims, n_out):
-    tot = np.zeros(n_out)
-    n = 0
+def _epoch_means(loader, step, flat_ims, width):
+    """Row-weighted means of whatever ``step(x, y)`` returns (a ``width``-tuple of floats) over one pass."""
+    sums, rows = np.zeros(width), 0
     for x, y in loader:
-        if flat_ims:
-            x = x.view(x.shape[0], -1)
-        out = step(x, y)
-        tot += np.asarray(out, dtype=np.float64) * x.shape[0]
-        n += len(x)
-    return tot / max(n, 1)
+        xb = x.view(x.shape[0], -1) if flat_ims else x
+        sums += np.asarray(step(xb, y), dtype=np.float64) * xb.shape[0]
+        rows += len(xb)
+    return sums / max(rows, 1)
+
+
+class _RunLog(object):
+    """Per-epoch curves of one run; `as_reference_tuple` lays them out the way the reference returns them."""
+
+    def __init__(self, epochs):
+        self.objective = np.zeros(epochs)
+        self.train_nll = np.zeros(epochs)
+        self.dev_nll = np.zeros(epochs)
+        self.train_err = np.zeros(epochs)
+        self.dev_err = np.zeros(epochs)
+        self.q, self.posterior, self.log_marginal, self.exact_elbo = [], [], [], []
+
+    @staticmethod
+    def _stack(rows):
+        return np.stack(rows, axis=0) if rows else rows
+
+    def as_reference_tuple(self, track_posterior, track_exact_elbo, basedir):
+        q, post, marg = ((self._stack(self.q), self._stack(self.posterior), self._stack(self.log_marginal))
+                         if track_posterior else (self.q, self.posterior, self.log_marginal))
+        exact = self._stack(self.exact_elbo) if track_exact_elbo else self.exact_elbo
+        return (self.objective, self.train_nll, self.dev_nll, self.train_err, self.dev_err, q, post, marg, exact,
+                basedir)
 
 
 def train_fc_DUN(net, name, save_dir, batch_size, nb_epochs, train_loader, val_loader,
@@ -32,85 +55,60 @@ def train_fc_DUN(net, name, save_dir, batch_size, nb_epochs, train_loader, val_l
                  track_posterior=False, track_exact_ELBO=False, tags=None,
                  load_path=None, save_freq=None, q_nograd_its=0):
     basedir = os.path.join(save_dir, name, next(tempfile._get_candidate_names()))
-    media_dir = basedir + '/media/'
-    models_dir = basedir + '/models/'
-    mkdir(models_dir)
-    mkdir(media_dir)
-
+    models_dir = os.path.join(basedir, "models")
+    for d in (models_dir, os.path.join(basedir, "media")):
+        mkdir(d + "/")
     if seed is not None:
         torch.manual_seed(seed)
         if cuda:
             torch.cuda.manual_seed(seed)
 
-    marginal_loglike_estimate = np.zeros(nb_epochs)
-    train_mean_predictive_loglike = np.zeros(nb_epochs)
-    dev_mean_predictive_loglike = np.zeros(nb_epochs)
-    err_train = np.zeros(nb_epochs)
-    err_dev = np.zeros(nb_epochs)
-    true_d_posterior, approx_d_posterior, true_likelihood, exact_ELBO = [], [], [], []
-
-    best_epoch = 0
-    best_marginal_loglike = -np.inf
+    log = _RunLog(nb_epochs)
+    q_logits = net.prob_model.q_logits
     if q_nograd_its > 0:
-        net.prob_model.q_logits.requires_grad = False
+        q_logits.requires_grad = False
+    best_value, best_epoch, epochs_run = -np.inf, 0, 0
+    started = time.time()
 
-    tic0 = time.time()
-    i = -1
-    for i in range(nb_epochs):
-        if q_nograd_its > 0 and i == q_nograd_its:
-            net.prob_model.q_logits.requires_grad = True
+    for ep in range(nb_epochs):
+        epochs_run = ep + 1
+        if q_nograd_its > 0 and ep == q_nograd_its:
+            q_logits.requires_grad = True
 
         net.set_mode_train(True)
-        tic = time.time()
-        marginal_loglike_estimate[i], train_mean_predictive_loglike[i], err_train[i] = \
-            _weighted_pass(train_loader, net.fit, flat_ims, 3)
-        toc = time.time()
-
-        print('\n depth approx posterior', net.prob_model.current_posterior.data.cpu().numpy())
-        print("it %d/%d, ELBO/evidence %.4f, pred minus loglike = %f, err = %f" %
-              (i, nb_epochs, marginal_loglike_estimate[i], train_mean_predictive_loglike[i], err_train[i]), end="")
-        cprint('r', '   time: %f seconds\n' % (toc - tic))
+        t0 = time.time()
+        log.objective[ep], log.train_nll[ep], log.train_err[ep] = _epoch_means(train_loader, net.fit, flat_ims, 3)
+        q_now = net.prob_model.current_posterior.data.cpu().numpy()
+        print("\n depth approx posterior", q_now)
+        print("it %d/%d, ELBO/evidence %.4f, pred minus loglike = %f, err = %f"
+              % (ep, nb_epochs, log.objective[ep], log.train_nll[ep], log.train_err[ep]), end="")
+        cprint("r", "   time: %f seconds\n" % (time.time() - t0))
         net.update_lr()
 
         if track_posterior:
-            approx_d_posterior.append(net.prob_model.current_posterior.data.cpu().numpy())
-            exact_posterior, log_marginal_over_depth = net.get_exact_d_posterior(train_loader, train_bn=True,
-                                                                                 logposterior=False)
-            true_d_posterior.append(exact_posterior.data.cpu().numpy())
-            true_likelihood.append(log_marginal_over_depth)
+            posterior, log_marginal = net.get_exact_d_posterior(train_loader, train_bn=True, logposterior=False)
+            log.q.append(q_now)
+            log.posterior.append(posterior.data.cpu().numpy())
+            log.log_marginal.append(log_marginal)
         if track_exact_ELBO:
-            exact_ELBO.append(net.get_exact_ELBO(train_loader, train_bn=True))
+            log.exact_elbo.append(net.get_exact_ELBO(train_loader, train_bn=True))
 
-        if i % nb_its_dev == 0:
-            tic = time.time()
-            dev_mean_predictive_loglike[i], err_dev[i] = _weighted_pass(val_loader, net.eval, flat_ims, 2)
-            toc = time.time()
-            cprint('g', '     pred minus loglike = %f, err = %f\n' % (dev_mean_predictive_loglike[i], err_dev[i]), end="")
-            cprint('g', '    time: %f seconds\n' % (toc - tic))
+        if ep % nb_its_dev == 0:
+            t0 = time.time()
+            log.dev_nll[ep], log.dev_err[ep] = _epoch_means(val_loader, net.eval, flat_ims, 2)
+            cprint("g", "     pred minus loglike = %f, err = %f\n" % (log.dev_nll[ep], log.dev_err[ep]), end="")
+            cprint("g", "    time: %f seconds\n" % (time.time() - t0))
 
-        if save_freq is not None and i % save_freq == 0:
-            net.save(models_dir + '/theta_last.dat')
-
-        if marginal_loglike_estimate[i] > best_marginal_loglike:
-            best_marginal_loglike = marginal_loglike_estimate[i]
-            best_epoch = i
-            cprint('b', 'best marginal loglike: %f' % best_marginal_loglike)
-            if i % 2 == 0:
-                net.save(models_dir + '/theta_best.dat')
-
-        if early_stop is not None and (i - best_epoch) > early_stop:
-            cprint('r', '   stopped early!\n')
+        if save_freq is not None and ep % save_freq == 0:
+            net.save(os.path.join(models_dir, "theta_last.dat"))
+        if log.objective[ep] > best_value:
+            best_value, best_epoch = log.objective[ep], ep
+            cprint("b", "best marginal loglike: %f" % best_value)
+            if ep % 2 == 0:
+                net.save(os.path.join(models_dir, "theta_best.dat"))
+        if early_stop is not None and ep - best_epoch > early_stop:
+            cprint("r", "   stopped early!\n")
             break
 
-    runtime_per_it = (time.time() - tic0) / float(i + 1)
-    cprint('r', '   average time: %f seconds\n' % runtime_per_it)
-
-    if track_posterior:
-        approx_d_posterior = np.stack(approx_d_posterior, axis=0)
-        true_d_posterior = np.stack(true_d_posterior, axis=0)
-        true_likelihood = np.stack(true_likelihood, axis=0)
-    if track_exact_ELBO:
-        exact_ELBO = np.stack(exact_ELBO, axis=0)
-
-    return marginal_loglike_estimate, train_mean_predictive_loglike, dev_mean_predictive_loglike, err_train, err_dev, \
-        approx_d_posterior, true_d_posterior, true_likelihood, exact_ELBO, basedir
+    cprint("r", "   average time: %f seconds\n" % ((time.time() - started) / float(max(epochs_run, 1))))
+    return log.as_reference_tuple(track_posterior, track_exact_ELBO, basedir)
