@@ -2,20 +2,27 @@
 //
 // C[M,N] = epi(sum_k A(m,k) B(k,n)) on v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), so the
 // trunk keeps the reference's fp32 numerics (north-star: 1e-5 relative) while running on the matrix cores.
-// Workgroup = 256 threads = 4 waves (2x2), tile 128x128x32, each wave a 64x64 sub-tile = 2x2 MFMA 32x32
-// accumulators.  Operand tiles are staged global -> registers -> LDS, double buffered, one barrier per K
-// tile; the register prefetch of tile t+1 is in flight while tile t is multiplied.
+// Three kernels share one epilogue:
+//   gemm_f32_dma4_kernel  whole 128x128 tiles, 16-byte aligned operands, >= 128 tiles (every trunk GEMM of the wide
+//                         config): LDS-DMA staging through four 16-deep stages, mid-tile barrier, counted waits,
+//                         optional split-K (see the comment above the kernel);
+//   gemm_f32_dma_kernel   the same problems with two 32-deep buffers and the barrier at the tile end (A/B reference,
+//                         and operands beyond 32-bit byte offsets);
+//   gemm_f32_kernel       everything else (ragged, unaligned, or too small to fill the chip): operand tiles staged
+//                         global -> registers -> LDS, double buffered, one barrier per K tile; 128x128 tiles or, under
+//                         128 tiles, 64x64 tiles; optional split-K.
+// Workgroup = 256 threads = 4 waves (2x2); a wave owns a 64x64 (or 32x32) sub-tile = 2x2 (1x1) MFMA accumulators.
 //
 // Operands keep their global orientation in LDS, so no transposes are ever materialised:
-//   K-contiguous operand (x / h / dU rows, Linear weight rows): LDS [128][32+4] floats; a lane reads its
-//     four k values with one ds_read_b128 (144-B row stride: conflict-free for the 16-lane b128 groups);
-//   M/N-contiguous operand (W in dX = dU W, dU^T and H in dW = dU^T H): LDS [32][128]; a lane reads one
-//     float per MFMA with ds_read_b32, 32 consecutive lanes on 32 consecutive banks.
+//   K-contiguous operand (x / h / dU rows, Linear weight rows): a lane reads its four k values with one ds_read_b128
+//     (register-staged tiles: [T][32+4] floats, 144-B row stride; DMA tiles: unpadded with an XOR chunk swizzle);
+//   M/N-contiguous operand (W in dX = dU W, dU^T and H in dW = dU^T H): LDS [k][T]; a lane reads one float per MFMA
+//     with ds_read_b32, 32 consecutive lanes on 32 consecutive banks.
 // Both forms feed the MFMA with k(step s=(t,e), lane half h) = 8t + 4h + e, so any pairing is consistent.
 //
-// Epilogues (all optional, fused): + bias[n], ReLU, + R[m,n] (residual / running gradient), + U[m,:] V[:,n]
-// (the head's rank-O gradient contribution), and per-128-row-tile column sums of C and C^2 (BatchNorm
-// batch statistics, reduced later in fp64).
+// Epilogues (all optional, fused): + bias[n], ReLU, + R[m,n] (residual / running gradient, may alias C), + U[m,:] V[:,n]
+// (the head's rank-O gradient contribution), and per-row-tile column sums of C and C^2 in fp64 (BatchNorm batch
+// statistics, reduced later in a fixed order).
 #include <stdlib.h>
 
 #include "common.h"
