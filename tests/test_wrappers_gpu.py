@@ -380,3 +380,30 @@ def test_odd_shapes_against_fp64_oracle_on_device(din, W, L, B, C):
         ref = g64[k]
         err = float((mine.double() - ref).norm() / ref.norm().clamp_min(1e-30))
         assert err < 2e-3, (k, err)   # l2 over the tensor: a ReLU sign flip near 0 moves single entries
+
+
+def test_vec_forward_and_vec_predict_cold_path():
+    """vec_forward / vec_predict (plotting-only in the reference: torch ops over the same parameters): an all-ones mask
+    is the deepest exit, a prefix mask is that depth's exit, both equal to the kernel path's eval forward and to the
+    oracle's fc_vec_forward."""
+    c = Case("cls_fc")
+    net = build_net(c)
+    x = c.t("x").cuda()
+    net.model.eval()
+    L = c.cfg["L"]
+    with torch.no_grad():
+        act = net.model.forward(x)                      # [D, B, C] through the HIP kernels
+        full = net.model.vec_forward(x, torch.ones(L, device="cuda"))
+        assert rel_err(full.cpu(), act[-1].cpu()) < 1e-5
+        for k in range(L + 1):
+            mask = torch.cat([torch.ones(k), torch.zeros(L - k)]).cuda()
+            assert rel_err(net.model.vec_forward(x, mask).cpu(), act[k].cpu()) < 1e-5
+        p = O.params_from_reference_state_dict({k: v.cpu() for k, v in net.model.state_dict().items()}, L)
+        mask = torch.tensor([1.0, 0.0, 1.0, 0.0][:L])
+        ref = O.fc_vec_forward(p, c.t("x"), mask)
+        assert rel_err(net.model.vec_forward(x, mask.cuda()).cpu(), ref) < 1e-5
+    bin_mat = torch.tensor([[1.0] * L, [1.0] + [0.0] * (L - 1)], device="cuda")
+    probs = net.vec_predict(x, bin_mat)
+    assert probs.shape == (2, x.shape[0], c.cfg["O"])
+    assert rel_err(probs[0].cpu(), torch.softmax(act[-1], dim=1).cpu()) < 1e-5
+    assert rel_err(probs[1].cpu(), torch.softmax(act[1], dim=1).cpu()) < 1e-5
