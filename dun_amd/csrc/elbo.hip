@@ -665,6 +665,131 @@ __global__ __launch_bounds__(256) void predict_softmax_kernel(const float* __res
     }
 }
 
+// LDS-staged depth-marginal class probabilities (16-byte aligned problems).  The kernel above walks D depths x 16
+// passes of lane-group shuffles per workgroup as one serial chain (100 us for 4096 rows x 12 exits x 10 classes).
+// Here the rows of one depth are one contiguous run: it is prefetched into registers with 16-byte lane accesses while
+// the previous depth is reduced out of LDS, G lanes own a row (G = 1 for C <= 32: a thread per row, no shuffles) and
+// keep its running sum_d q_d softmax(a_d) in registers; probabilities leave through the same LDS tile.
+template <int G, int KMAX>
+__global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* __restrict__ act,
+                                                                  const float* __restrict__ q, int D, int B, int C,
+                                                                  float* __restrict__ probs,
+                                                                  const int64_t* __restrict__ y,
+                                                                  double* __restrict__ partials, int nparts) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    __shared__ double red[4];
+    constexpr int RPP = 256 / G;  // rows per pass
+    constexpr int NF = 8;         // float4 per thread and tile: RPP * C <= 8192 floats
+    const int part = blockIdx.x, tid = threadIdx.x;
+    const int gl = tid % G, grp = tid / G;
+    const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
+    double nll = 0.0, nerr = 0.0;
+    for (int r0 = part * ROWS_PER_BLOCK; r0 < row_end; r0 += RPP) {
+        const int nrows = min(RPP, row_end - r0);
+        const int nfl = nrows * C;
+        const bool mine = grp < nrows;
+        float pr[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) pr[k] = 0.f;
+        f32x4 pre[NF];
+        auto fetch = [&](int d) {
+            const float* src = act + ((size_t)d * B + r0) * C;  // multiple of 4 floats (r0 % 4 == 0, B*C % 4 == 0)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int i = (f * 256 + tid) * 4;
+                pre[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i + 3 < nfl) {
+                    pre[f] = *reinterpret_cast<const f32x4*>(src + i);
+                } else if (i < nfl) {
+                    for (int e = 0; e < 4; ++e)
+                        if (i + e < nfl) pre[f][e] = src[i + e];
+                }
+            }
+        };
+        fetch(0);
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int i = (f * 256 + tid) * 4;
+                if (i < nfl) *reinterpret_cast<f32x4*>(tile + i) = pre[f];  // (tile is padded to a multiple of 4 floats)
+            }
+            __syncthreads();
+            if (d + 1 < D) fetch(d + 1);
+            if (mine) {
+                const float* a = tile + grp * C;
+                float v[KMAX];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int j = gl + k * G;
+                    v[k] = j < C ? a[j] : -INFINITY;
+                    mx = fmaxf(mx, v[k]);
+                }
+                mx = group_max<G>(mx);
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    v[k] = expf(v[k] - mx);  // exp(-inf) = 0 for the padding
+                    s += v[k];
+                }
+                s = group_sum<G>(s);
+                const float sc = q[d] / s;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) pr[k] += sc * v[k];
+            }
+            __syncthreads();
+        }
+        if (mine) {
+            float* o = tile + grp * C;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (gl + k * G < C) o[gl + k * G] = pr[k];
+            if (partials) {
+                const int yb = (int)y[r0 + grp];
+                float py = 0.f, best = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int j = gl + k * G;
+                    if (j < C) {
+                        if (j == yb) py = pr[k];
+                        if (pr[k] > best) { best = pr[k]; bi = j; }
+                    }
+                }
+                py = group_sum<G>(py);
+#pragma unroll
+                for (int off = G / 2; off > 0; off >>= 1) {
+                    const float ob = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (gl == 0) {
+                    nll += (double)(-logf(py));
+                    nerr += (bi != yb) ? 1.0 : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        float* dst = probs + (size_t)r0 * C;  // r0 * C % 4 == 0
+        for (int i = tid * 4; i < nfl; i += 1024) {
+            if (i + 3 < nfl) {
+                *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(tile + i);
+            } else {
+                for (int e = i; e < nfl; ++e) dst[e] = tile[e];
+            }
+        }
+        __syncthreads();  // the next pass overwrites the tile
+    }
+    if (partials) {
+        const double t0 = block_sum<256, double>(nll, red);
+        const double t1 = block_sum<256, double>(nerr, red);
+        if (tid == 0) {
+            partials[part] = t0;
+            partials[nparts + part] = t1;
+        }
+    }
+}
+
 // ---- host side ----
 static int softmax_group(int C, int* kmax) {
     int G = 2;
@@ -860,7 +985,26 @@ extern "C" int dun_predict_softmax(const float* act, const float* q, int D, int 
     const int nparts = dun_predict_num_partials(B, C > 1 ? C : 2);
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* part = metrics ? partials : nullptr;
-    DUN_SOFTMAX_DISPATCH(predict_softmax_kernel, G, km, dim3(nparts), s, act, q, D, B, C, probs, y, part, nparts);
+    const bool lds_ok = ((long long)B * C) % 4 == 0 && aligned16(act) && aligned16(probs);
+    if (lds_ok) {
+        int g = 1;
+        while (g * 32 < C) g <<= 1;
+        const size_t lds = ((size_t)(256 / g) * C + 4) * sizeof(float);
+#define DUN_PS(GG, KK)                                                                                            \
+    hipLaunchKernelGGL((predict_softmax_lds_kernel<GG, KK>), dim3(nparts), dim3(256), lds, s, act, q, D, B, C, probs, y, \
+                       part, nparts)
+        if (C <= 10) DUN_PS(1, 10);
+        else if (C <= 16) DUN_PS(1, 16);
+        else if (g == 1) DUN_PS(1, 32);
+        else if (g == 2) DUN_PS(2, 32);
+        else if (g == 4) DUN_PS(4, 32);
+        else if (g == 8) DUN_PS(8, 32);
+        else if (g == 16) DUN_PS(16, 32);
+        else DUN_PS(32, 32);
+#undef DUN_PS
+    } else {
+        DUN_SOFTMAX_DISPATCH(predict_softmax_kernel, G, km, dim3(nparts), s, act, q, D, B, C, probs, y, part, nparts);
+    }
     DUN_LAUNCH_CHECK();
     if (metrics) {
         hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);

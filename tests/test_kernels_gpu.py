@@ -196,6 +196,15 @@ def test_elbo_softmax_sizes(be, D, B, C):
     cf = O.elbo_grads_closed_form(act.double(), y, False, N, O.q_probs(ql.double()), q_logits=ql.double(),
                                   logprior=logprior, prior_loglikes=z)
     assert rel_err(dact, cf["dact"]) < 1e-5
+    # depth-marginal class probabilities + fused metrics on the same shapes (LDS-staged and fallback kernels)
+    q = O.q_probs(ql)
+    probs, _, m = be.predict(dev(act), dev(q), False, y=dev(y))
+    pr = O.marginalise_predict(act.double(), q.double(), softmax=True)
+    assert rel_err(probs.cpu(), pr) < 1e-5
+    nll_ref = -torch.log(pr[torch.arange(B), y]).sum().item()
+    assert abs(m.cpu()[0].item() - nll_ref) < 1e-5 * abs(nll_ref) + 1e-9
+    # (argmax ties between classes do not occur on random logits)
+    assert m.cpu()[1].item() == float((pr.max(dim=1)[1] != y).sum())
 
 
 # B >= 2^21 takes the depth-walking kernel: ragged last chunk, and D > 64 (more than one depth group per chunk)
