@@ -274,6 +274,21 @@ def test_sharded_path_world1_matches_unsharded():
         quiet(shard, net, sync_bn=True)
         got = [net.fit(x, y) for _ in range(2)]
         assert np.allclose(got, want, rtol=1e-6)
+        # the collectives the N-GPU path issues, through RCCL itself (Shard skips them at world size 1): fp64 SUM,
+        # asynchronous SUM on a slice of the flat gradient buffer, MAX, broadcast, barrier
+        t = torch.arange(128, dtype=torch.float64, device="cuda").view(2, 64)
+        dist.all_reduce(t)
+        piece = net.model.flat_grads[8:1000]
+        before = piece.clone()
+        h = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+        h.wait()
+        m = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        dist.broadcast(net.model.flat_params, src=0)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(t.view(-1), torch.arange(128, dtype=torch.float64, device="cuda"))
+        assert torch.equal(piece, before) and float(m) == 1.5
         assert torch.equal(net.model.flat_params, ref.model.flat_params)
         assert torch.equal(net.model.running_var, ref.model.running_var)
         assert np.allclose(net.eval(x, y), ref.eval(x, y), rtol=1e-6)
