@@ -145,6 +145,15 @@ def timed(fn, n, stream_sync=True):
     return e0.elapsed_time(e1) / n
 
 
+def gemm_kernel_name(M, N, K, a_kc, b_kc):
+    """Which GEMM kernel the library dispatches for this shape (dun_amd/csrc/gemm.hip: gemm_f32)."""
+    small = ((M + 127) // 128) * ((N + 127) // 128) < 128
+    if not small and M % 128 == 0 and N % 128 == 0 and K % 32 == 0:
+        return "gemm_f32_dma4_kernel<A_KC=%d,B_KC=%d>" % (a_kc, b_kc)
+    mi = 1 if small else 2
+    return "gemm_f32_kernel<A_KC=%d,B_KC=%d,MI=%d> (%dx%d tiles)" % (a_kc, b_kc, mi, 64 * mi, 64 * mi)
+
+
 def kernel_rooflines(net, B_local, reps):
     """Live per-kernel timings on the buffers of the training step (same shapes, same data)."""
     from dun_amd import kernels
@@ -158,7 +167,7 @@ def kernel_rooflines(net, B_local, reps):
     flops = 2.0 * B_local * W * W
     scratch = torch.empty_like(Z0)
     ms = timed(lambda: be.gemm(H0, w0, B_local, W, W, bias=b0, relu=True, colstats=True, out=scratch), reps)
-    out["gemm_fwd"] = dict(kernel="gemm_f32_dma4_kernel<A_KC=1,B_KC=1> (block forward: bias+ReLU+BN stats)",
+    out["gemm_fwd"] = dict(kernel=gemm_kernel_name(B_local, W, W, 1, 1) + " (block forward: bias+ReLU+BN stats)",
                            ms=ms, tflops=flops / ms / 1e9)
     u1 = torch.randn(B_local, 1, device=Z0.device) * 1e-3
     v1 = model.stacked["w_out"]
@@ -166,12 +175,12 @@ def kernel_rooflines(net, B_local, reps):
     scratch.copy_(buf.G)
     ms = timed(lambda: be.gemm(buf.dU, w0, B_local, W, W, a_kcontig=True, b_kcontig=False, R=scratch, U=u1, V=v1,
                                out=scratch), reps)
-    out["gemm_dx"] = dict(kernel="gemm_f32_dma4_kernel<A_KC=1,B_KC=0> (dX = dU W + g + dact w_out, in place)", ms=ms, tflops=flops / ms / 1e9)
+    out["gemm_dx"] = dict(kernel=gemm_kernel_name(B_local, W, W, 1, 0) + " (dX = dU W + g + dact w_out, in place)", ms=ms, tflops=flops / ms / 1e9)
     gw = model.stacked_grad["w"][0]
     skws = torch.empty(2 * W * W, device=Z0.device)
     ms = timed(lambda: be.gemm(buf.dU, H0, W, W, B_local, a_kcontig=False, b_kcontig=False, out=gw, splitk_ws=skws),
                reps)
-    out["gemm_dw"] = dict(kernel="gemm_f32_dma4_kernel<A_KC=0,B_KC=0>, split-K 2 + splitk_sum (dW = dU^T H)", ms=ms, tflops=flops / ms / 1e9)
+    out["gemm_dw"] = dict(kernel=gemm_kernel_name(W, W, B_local, 0, 0) + ", split-K + splitk_sum (dW = dU^T H)", ms=ms, tflops=flops / ms / 1e9)
     # head over all D*B hidden rows (O=1): reads 4*D*B*W bytes once
     Hall = buf.H.view(D * B_local, W)
     ms = timed(lambda: be.head_forward(Hall, model.stacked["w_out"], model.stacked["b_out"]), reps)
