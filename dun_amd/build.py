@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdun_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "elbo.hip", "head.hip", "trunk.hip"]
+SOURCES = ["api.hip", "gemm.hip", "elbo.hip", "head.hip", "trunk.hip", "smallnet.hip"]
 ARCH = "gfx950"
 
 

@@ -21,6 +21,12 @@ int head_forward(const float* H, const float* w, const float* b, int rows, int K
 int head_backward(const float* H, const float* w, const float* dact, int rows, int K, int O, float* dw, float* db,
                   float* dH, float* ws, size_t ws_floats, hipStream_t s);
 size_t head_backward_ws(int rows, int K, int O);
+// smallnet.hip: one launch per block for widths <= 128 (toy / UCI configurations)
+bool sn_shape_ok(int B, int W);
+size_t sn_extra_ws_floats(int B, int W);
+bool sn_eligible(const dun_fc_ctx* c, bool backward);
+int sn_forward_block(const dun_fc_ctx* c, int i, hipStream_t s);
+int sn_backward_blocks(const dun_fc_ctx* c, float* dU2, hipStream_t s);
 
 // rows per column-reduction partial: 128, or 32 for small batches (four times the workgroups, a quarter of the serial
 // row loop: the UCI-sized nets are latency bound)
@@ -573,15 +579,20 @@ static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
 
 using namespace dun;
 
-extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
-    (void)din;
+// workspace of the tiled path, rounded to 256 bytes; the small-net path keeps its second dU buffer behind it
+static size_t base_workspace_floats(int B, int W, int O, int L) {
     const size_t P = (size_t)ceil_div(B, 64);  // upper bound of the GEMM's row tiles (and of num_slabs(B))
     const size_t cols = 4 * P * (size_t)W;  // fp64 [2][P][W] forward statistics partials
     const size_t hb = head_backward_ws((L + 1) * B, W, O);
     const size_t sk = L > 0 ? 4 * (size_t)W * W : 0;  // split-K partials of dW = dU^T H (2 ranges at C3, 4 on small nets)
     size_t m = cols > hb ? cols : hb;
     if (sk > m) m = sk;
-    return m + 64;
+    return (m + 64 + 63) / 64 * 64;
+}
+
+extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
+    (void)din;
+    return base_workspace_floats(B, W, O, L) + sn_extra_ws_floats(B, W);
 }
 
 #define STREAM static_cast<hipStream_t>(stream)
@@ -606,6 +617,11 @@ extern "C" int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream) {
     int rc = check_ctx(c, "dun_fc_forward");
     if (rc) return rc;
     if ((rc = input_layer(c, STREAM))) return rc;
+    if (sn_eligible(c, false)) {  // small net: one column-owned launch per block
+        for (int i = 0; i < c->depth; ++i)
+            if ((rc = sn_forward_block(c, i, STREAM))) return rc;
+        return head(c, STREAM);
+    }
     for (int i = 0; i < c->depth; ++i) {
         if ((rc = block_linear(c, i, STREAM, /*reduce_stats=*/false))) return rc;
         if ((rc = block_norm(c, i, (double)c->B, STREAM, /*from_partials=*/c->train != 0))) return rc;
@@ -636,6 +652,13 @@ extern "C" int dun_fc_bwd_end(const dun_fc_ctx* c, dun_stream_t stream) {
 extern "C" int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream) {
     int rc = check_bwd(c, "dun_fc_backward");
     if (rc) return rc;
+    if (sn_eligible(c, true)) {  // small net: head gradients, then one column-owned launch per block + input layer
+        const int rows = (c->depth + 1) * c->B;
+        if ((rc = head_backward(c->H, c->p.w_out, c->dact, rows, c->W, c->O, c->g.w_out, c->g.b_out, nullptr, c->ws,
+                                c->ws_floats, STREAM)))
+            return rc;
+        return sn_backward_blocks(c, c->ws + base_workspace_floats(c->B, c->W, c->O, c->L), STREAM);
+    }
     if ((rc = bwd_begin(c, STREAM))) return rc;
     for (int i = c->L - 1; i >= 0; --i) {
         if ((rc = bwd_block_reduce(c, i, STREAM))) return rc;

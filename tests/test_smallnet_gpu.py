@@ -1,0 +1,142 @@
+"""GPU parity of the column-owned small-net kernels (dun_amd/csrc/smallnet.hip) behind dun_fc_forward /
+dun_fc_backward, against (a) the staged C entries, which always run the tiled-GEMM kernels, and (b) an fp64
+autograd evaluation of the block stack (the golden-pinned oracle covers the same path through DUN_VI.fit on the
+c1/c2 fixtures in test_wrappers_gpu.py).  fp32, different summation orders: tolerances are relative to the largest magnitude of each tensor.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (B, din, W, L, O, residual): toy / UCI shapes, padded LDS stride (W/4 even), several row chunks, ragged batches,
+# 4-float input rows (vector dW_in path), the narrowest width
+SHAPES = [(300, 1, 100, 3, 1, True), (512, 13, 100, 10, 1, True), (512, 9, 128, 2, 3, True),
+          (1000, 8, 64, 3, 1, False), (37, 5, 4, 2, 2, True), (2000, 13, 40, 2, 1, True), (256, 16, 100, 1, 1, True)]
+
+
+def make(B, din, W, L, Oo, residual, seed=0):
+    from dun_amd import kernels
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_MLP, arq_uncert_fc_resnet
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    torch.manual_seed(seed)
+    model = (arq_uncert_fc_resnet if residual else arq_uncert_fc_MLP)(din, Oo, W, L).cuda()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        model.stacked["gamma"].copy_(1.0 + 0.2 * torch.randn(L, W, generator=g))
+        model.stacked["beta"].copy_(0.2 * torch.randn(L, W, generator=g))
+    x = torch.randn(B, din, generator=g).cuda()
+    return model, x, kernels.backend(), g
+
+
+def close(a, b, tol, what):
+    a, b = a.double(), b.double()
+    scale = max(float(b.abs().max()), 1e-30)
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, "%s: max error %.3g of the largest magnitude (tolerance %.1g)" % (what, err, tol)
+
+
+def staged_forward(be, buf, L, B):
+    be.fc_input_layer(buf)
+    for i in range(L):
+        be.fc_block_linear(buf, i)
+        be.fc_block_norm(buf, i, B)
+    be.fc_head(buf)
+
+
+def staged_backward(be, buf, L, B):
+    be.fc_bwd_begin(buf)
+    for i in range(L - 1, -1, -1):
+        be.fc_bwd_block_reduce(buf, i)
+        be.fc_bwd_block_apply(buf, i, B)
+    be.fc_bwd_end(buf)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_small_net_path_matches_tiled_path(shape):
+    from dun_amd import _lib
+    B, din, W, L, Oo, residual = shape
+    assert _lib.lib().dun_fc_workspace_floats(B, din, W, Oo, L) > B * W      # the shape takes the small-net path
+    model, x, be, g = make(*shape)
+    model.train()
+    rm0, rv0 = model.running_mean.clone(), model.running_var.clone()
+    b1 = be.fc_buffers(model, B, L, True)
+    b1.new_act(); b1.set_input(x)
+    be.fc_forward(b1)
+    rm1, rv1 = model.running_mean.clone(), model.running_var.clone()
+    model.running_mean.copy_(rm0); model.running_var.copy_(rv0)
+    b2 = be.fc_buffers(model, B, L, True)
+    b2.new_act(); b2.set_input(x)
+    staged_forward(be, b2, L, B)
+    close(b1.H, b2.H, 2e-4, "hidden states")   # two fp32 summation orders through BatchNorm (din = 1: near-constant columns)
+    close(b1.act, b2.act, 2e-4, "act_vec")
+    close(b1.Z, b2.Z, 2e-4, "ReLU(Linear)")
+    close(b1.bn_mean[:L], b2.bn_mean[:L], 1e-4, "batch mean")
+    close(b1.bn_rstd[:L], b2.bn_rstd[:L], 2e-4, "batch rstd")
+    close(rm1, model.running_mean, 1e-4, "running mean")
+    close(rv1, model.running_var, 1e-4, "running var")
+    # backward from the SAME saved forward state (a ReLU pre-activation within rounding of 0 may otherwise take
+    # different sides in the two forwards and move single gradient entries by O(1/B))
+    for k in ("H", "Z", "bn_mean", "bn_rstd"):
+        getattr(b2, k).copy_(getattr(b1, k))
+    dact = (torch.randn(L + 1, B, Oo, generator=g) / B).cuda()
+    b1.ensure_backward(); b1.set_dact(dact)
+    model.flat_grads.fill_(float("nan"))
+    be.fc_backward(b1)
+    g1 = {k: v.clone() for k, v in model.stacked_grad.items()}
+    b2.ensure_backward(); b2.set_dact(dact)
+    model.flat_grads.fill_(float("nan"))
+    staged_backward(be, b2, L, B)
+    for k, v in model.stacked_grad.items():
+        assert bool(torch.isfinite(g1[k]).all()), k
+        close(g1[k], v, 5e-5, "gradient of " + k)
+    close(b1.G, b2.G, 5e-5, "gradient w.r.t. the input layer's output")
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[2], SHAPES[3]])
+def test_small_net_forward_backward_against_fp64_oracle(shape):
+    B, din, W, L, Oo, residual = shape
+    model, x, be, g = make(*shape, seed=3)
+    model.train()
+    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in model.stacked.items()}
+    buf = be.fc_buffers(model, B, L, True)
+    buf.new_act(); buf.set_input(x)
+    be.fc_forward(buf)
+    # fp64 forward of the same block stack (src/DUN/layers.py:38-42), written out here: z = ReLU(h W^T + b),
+    # BatchNorm over the batch (biased variance), residual add; shared head at every depth
+    h = x.double().cpu() @ p["w_in"].t() + p["b_in"]
+    acts = [h @ p["w_out"].t() + p["b_out"]]
+    for i in range(L):
+        z = torch.relu(h @ p["w"][i].t() + p["b"][i])
+        m, v = z.mean(0), z.var(0, unbiased=False)
+        n = (z - m) / torch.sqrt(v + 1e-5) * p["gamma"][i] + p["beta"][i]
+        h = h + n if residual else n
+        acts.append(h @ p["w_out"].t() + p["b_out"])
+    act = torch.stack(acts)
+    close(buf.act.cpu(), act.detach(), 1e-4, "act_vec vs fp64")
+    dact = (torch.randn(L + 1, B, Oo, generator=g) / B)
+    act.backward(dact.double())
+    buf.ensure_backward(); buf.set_dact(dact.cuda())
+    be.fc_backward(buf)
+    for k, v in model.stacked_grad.items():
+        close(v.cpu(), p[k].grad, 2e-3, "gradient of %s vs fp64 autograd" % k)   # ReLU-edge flips: see DESIGN.md 4
+
+
+def test_small_net_eval_and_truncated_depth():
+    B, din, W, L, Oo, residual = 300, 1, 100, 4, 1, True
+    model, x, be, g = make(B, din, W, L, Oo, residual, seed=5)
+    with torch.no_grad():
+        model.running_mean.copy_(0.1 * torch.randn(L, W, generator=g))
+        model.running_var.copy_(0.5 + torch.rand(L, W, generator=g))
+    model.eval()
+    for depth in (L, 2):
+        b1 = be.fc_buffers(model, B, depth, False)
+        b1.new_act(); b1.set_input(x)
+        be.fc_forward(b1)
+        b2 = be.fc_buffers(model, B, depth, False)
+        b2.new_act(); b2.set_input(x)
+        staged_forward(be, b2, depth, B)
+        assert b1.act.shape[0] == depth + 1
+        close(b1.act, b2.act, 2e-5, "eval act_vec at depth %d" % depth)
+        close(b1.H, b2.H, 2e-5, "eval hidden states at depth %d" % depth)
