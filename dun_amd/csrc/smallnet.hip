@@ -11,9 +11,12 @@
 //             the previous launch left in global memory: the only data that crosses workgroups);
 //             BatchNorm+ReLU backward on its columns -> dU_i[:,c], dgamma, dbeta, db_i;  dW_i[c,:] = dU_i[:,c]^T h_i.
 //   The last backward launch does the same gradient update for the input layer and dW_in = g^T x, db_in.
-// The contractions run on the vector ALUs (fmaf chains): every operand row is staged once through LDS with coalesced
-// 16-byte loads and read back row-per-thread, the four weight rows/columns of the workgroup are wave-uniform loads.
-// MFMA tiles would leave W/16 = 7 workgroups on a 256-CU chip; this regime is latency bound, not a roofline claim.
+// The [rows, W] x [W, 4] contraction runs on the vector ALUs with K split over the 16 lanes of a DPP row: a lane
+// keeps the weights of its (up to two) 16-byte K steps in registers for the whole launch, loads the matching 16 bytes
+// of four rows per wave instruction straight from global memory (a row's lanes read consecutive addresses), and the
+// four column sums are combined across the 16 lanes with DPP adds: no LDS staging, no barrier, no uniform-operand
+// loads inside the loop.  MFMA tiles would leave W/16 = 7 workgroups on a 256-CU chip, and f32 MFMA runs at the
+// vector rate anyway; this regime is latency bound, not a roofline claim.
 #include <math.h>
 #include <stdlib.h>
 
@@ -21,54 +24,73 @@
 
 namespace dun {
 
-constexpr int SN_T = 1024;        // threads per workgroup: 16 waves, four per SIMD (latency hiding: 25 workgroups on 256 CUs)
-constexpr int SN_R = 256;         // rows per staged chunk (one per thread of a K part)
-constexpr int SN_KP = SN_T / SN_R;  // K parts: waves 4p..4p+3 contract the p-th quarter of K for the chunk's 256 rows
+constexpr int SN_T = 512;         // threads per workgroup: 8 waves, two per SIMD (256 VGPRs each)
+constexpr int SN_WAVES = SN_T / 64;
 constexpr int SN_NC = 4;          // columns owned by a workgroup
-constexpr int SN_MAX_RPT = 8;     // row chunks per workgroup -> B <= 2048 (g and z of every chunk stay in registers)
-constexpr int SN_MAX_W = 128;
-constexpr size_t SN_LDS_LIMIT = 160 * 1024;
-constexpr int SN_STAGE_U = 8;     // 16-byte loads in flight per thread while staging
+constexpr int SN_MAX_B = 2048;
+constexpr int SN_MAX_W = 128;     // 16 lanes x 2 K steps x 4 floats
+constexpr int SN_U = 16;          // row groups (of 4 rows per wave) in flight per batch of loads: 512 rows at once
 constexpr int SN_DW_U = 8;        // rows in flight per thread in the dW phase
 
-// row stride (floats) of the staged tile: S/4 odd, so that 16 consecutive lanes reading 16 bytes of their own row
-// hit 64 different banks
-static inline int sn_stride(int K) { return ((K >> 2) & 1) ? K : K + 4; }
-static inline size_t sn_tile_floats(int W) {
-    const size_t a = (size_t)SN_R * sn_stride(W);
-    return a > 8192 ? a : 8192;  // the dW phase reuses the tile as its [16][4][128] reduction buffer
-}
 // dynamic LDS carve (every offset a multiple of 16 bytes):
-//   [red: 4 x 8 doubles = 256 B][part: SN_KP x 256 rows x 4 floats = 16 KiB][dul: B x 4 floats (backward)][tile]
-constexpr size_t SN_OFF_PART = 256;
-constexpr size_t SN_OFF_DUL = SN_OFF_PART + (size_t)SN_KP * SN_R * 16;
-static inline size_t sn_fwd_lds(int W) { return SN_OFF_DUL + sn_tile_floats(W) * 4; }
-static inline size_t sn_bwd_lds(int B, int W) { return SN_OFF_DUL + (size_t)B * 16 + sn_tile_floats(W) * 4; }
+//   [red: 8 doubles][xbuf: 8 x 512 doubles, block sums][rbuf: 8 waves x 4 x 128 floats, dW combine][obuf: B x 4 floats]
+constexpr size_t SN_OFF_XBUF = 256;
+constexpr size_t SN_OFF_RBUF = SN_OFF_XBUF + (size_t)8 * SN_T * 8;
+constexpr size_t SN_OFF_OBUF = SN_OFF_RBUF + (size_t)SN_WAVES * 4 * 128 * 4;
+static inline size_t sn_lds(int B) { return SN_OFF_OBUF + (size_t)B * 16; }
 
 static const bool g_sn_off = getenv("DUN_SMALLNET") != nullptr && getenv("DUN_SMALLNET")[0] == '0';
 
 bool sn_shape_ok(int B, int W) {
     if (g_sn_off) return false;
-    if (W < 4 || W > SN_MAX_W || (W & 3) || B < 1 || B > SN_R * SN_MAX_RPT) return false;
-    return sn_bwd_lds(B, W) <= SN_LDS_LIMIT;
+    return W >= 4 && W <= SN_MAX_W && (W & 3) == 0 && B >= 1 && B <= SN_MAX_B;
 }
 size_t sn_extra_ws_floats(int B, int W) { return sn_shape_ok(B, W) ? (size_t)B * W : 0; }
 
-// sum of the values held by threads 0..255 (the threads that own rows); every thread of the workgroup gets the
-// totals.  The values go through LDS transposed ([NV][256] doubles in `xbuf`) so that only NV waves shuffle, one
-// double each: sixteen waves butterflying NV doubles apiece kept the LDS crossbar busy for 6 us.
+// ---- sums of four values over the 16 lanes of a DPP row (every lane gets the totals; fixed order) -------------
+// v_add_f32 with a DPP-permuted first operand, written as one asm block: the compiler's builtins give a
+// v_mov_b32_dpp + v_add_f32 pair per step (twice the instructions).  Stage-major order keeps three instructions
+// between a value's consecutive steps, which covers the two wait states a DPP read needs after a VALU write; the
+// leading s_nop covers the FMA that produced the inputs (the hazard recogniser does not look inside asm).
+__device__ __forceinline__ void sn_row16_sum4(f32x4& a) {
+    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
+}
+
+// sum of one value set per thread over the workgroup; every thread gets the totals.  The values go through LDS
+// transposed ([NV][512] doubles) so that only NV waves shuffle, one double each (waves butterflying NV doubles
+// apiece keep the LDS crossbar busy for microseconds).
 template <int NV>
 __device__ __forceinline__ void sn_block_sum(double (&v)[NV], double* red, double* xbuf) {
     const int t = threadIdx.x;
-    if (t < SN_R) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) xbuf[i * SN_R + t] = v[i];
-    }
+    for (int i = 0; i < NV; ++i) xbuf[i * SN_T + t] = v[i];
     __syncthreads();
     if (t < NV * 64) {
         const int i = t >> 6, l = t & 63;
-        const double* x = xbuf + i * SN_R + l;
-        double a = (x[0] + x[64]) + (x[128] + x[192]);
+        const double* x = xbuf + i * SN_T + l;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < SN_T / 64; q += 2) a += x[q * 64] + x[q * 64 + 64];
         a = wave_sum(a);
         if (l == 0) red[i] = a;
     }
@@ -78,55 +100,55 @@ __device__ __forceinline__ void sn_block_sum(double (&v)[NV], double* red, doubl
     __syncthreads();
 }
 
-// `rows` consecutive rows of a dense row-major [., W] matrix -> LDS tile with row stride S (coalesced 16-byte loads,
-// up to SN_STAGE_U of them in flight per thread).  step_row / step_col = SN_T / (W/4), SN_T % (W/4).
-__device__ __forceinline__ void sn_stage(float* tile, const float* src, int rows, int W, int S, int step_row,
-                                         int step_col) {
+// obuf[r][c] = sum_k A[r,k] wk[k][c] for all rows r < B, c < 4: lane (r4 = lane>>4, kp = lane&15) of wave w covers
+// K steps kp and kp+16 of rows (g*8 + w)*4 + r4.  wr[s][e][c]: weight of k = 4*(kp+16 s)+e, column c (zero beyond W).
+__device__ __forceinline__ void sn_rowdot(const float* __restrict__ A, int B, int W, const float (&wr)[2][4][4],
+                                          float* obuf) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r4 = lane >> 4, kp = lane & 15;
     const int nq = W >> 2;
-    const int nv = rows * nq;
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-    int row = threadIdx.x / nq, cq = threadIdx.x - row * nq;
-    for (int base = threadIdx.x; base < nv; base += SN_T * SN_STAGE_U) {
-        f32x4 v[SN_STAGE_U];
+    const bool has0 = kp < nq, has1 = kp + 16 < nq;
+    const int ngroups = (B + 4 * SN_WAVES - 1) / (4 * SN_WAVES);
+    const float* a0 = A + (has0 ? 4 * kp : 0);
+    const int off1 = has1 ? 64 : 0;
+    for (int g0 = 0; g0 < ngroups; g0 += SN_U) {
+        // branch-free loads (a branch per load serialises them behind vmcnt(0) waits): addresses are clamped into
+        // the matrix, K steps past W are zeroed afterwards (their weights are zero, but 0 * garbage may be NaN);
+        // rows past the batch compute garbage that is never stored
+        f32x4 h0[SN_U], h1[SN_U];
 #pragma unroll
-        for (int u = 0; u < SN_STAGE_U; ++u) {
-            const int i = base + u * SN_T;
-            if (i < nv) v[u] = s4[i];
+        for (int u = 0; u < SN_U; ++u) {
+            const int row = min(((g0 + u) * SN_WAVES + wv) * 4 + r4, B - 1);
+            const float* ar = a0 + (size_t)row * W;
+            h0[u] = *reinterpret_cast<const f32x4*>(ar);
+            h1[u] = *reinterpret_cast<const f32x4*>(ar + off1);
+        }
+        if (!has1) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < SN_U; ++u) h1[u] = zero;
+        }
+        if (!has0) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < SN_U; ++u) h0[u] = zero;
         }
 #pragma unroll
-        for (int u = 0; u < SN_STAGE_U; ++u) {
-            const int i = base + u * SN_T;
-            if (i < nv) *reinterpret_cast<f32x4*>(tile + row * S + cq * 4) = v[u];
-            row += step_row;
-            cq += step_col;
-            if (cq >= nq) { cq -= nq; ++row; }
+        for (int u = 0; u < SN_U; ++u) {
+            const int row = ((g0 + u) * SN_WAVES + wv) * 4 + r4;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = fmaf(h0[u][e], wr[0][e][c], a[c]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = fmaf(h1[u][e], wr[1][e][c], a[c]);
+            sn_row16_sum4(a);
+            if (kp == 0 && row < B) *reinterpret_cast<f32x4*>(obuf + 4 * row) = a;
         }
     }
-}
-
-// this wave's share of the W/4 sixteen-byte K steps (wave-uniform)
-__device__ __forceinline__ void sn_k_range(int nq, int* k_lo, int* k_hi) {
-    const int kp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-    const int per = (nq + SN_KP - 1) / SN_KP;
-    *k_lo = min(nq, kp * per);
-    *k_hi = min(nq, kp * per + per);
-}
-
-// combine the SN_KP partial sums of every row: valid in threads 0..255 (row = thread) after the call.
-// The call contains one barrier, which also ends every read of the staged tile.
-__device__ __forceinline__ f32x4 sn_combine_parts(f32x4 a, float* part) {
-    *reinterpret_cast<f32x4*>(part + 4 * threadIdx.x) = a;  // [kp][row][4]
-    __syncthreads();
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (threadIdx.x < SN_R) {
-#pragma unroll
-        for (int q = 0; q < SN_KP; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(part + 4 * (q * SN_R + threadIdx.x));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) r[c] += v[c];
-        }
-    }
-    return r;
 }
 
 struct SnFwdP {
@@ -141,7 +163,7 @@ struct SnFwdP {
     float* rstd;        // [W] train: 1/sqrt(var+eps) out
     float* running_mean;
     float* running_var;
-    int B, W, S, train, residual, step_row, step_col;
+    int B, W, train, residual;
     float eps, momentum;
     double count;
 #ifdef SN_PROFILE
@@ -155,68 +177,66 @@ struct SnFwdP {
 #define SN_STAMP(i) do { } while (0)
 #endif
 
-template <int RPT>
+template <int RPT>  // rows per thread in the elementwise phases: B <= 512 * RPT
 __global__ __launch_bounds__(SN_T) void sn_block_fwd_kernel(SnFwdP p) {
     extern __shared__ __attribute__((aligned(16))) char sn_smem[];
     double* red = reinterpret_cast<double*>(sn_smem);
-    float* part = reinterpret_cast<float*>(sn_smem + SN_OFF_PART);
-    float* tile = reinterpret_cast<float*>(sn_smem + SN_OFF_DUL);
+    double* xbuf = reinterpret_cast<double*>(sn_smem + SN_OFF_XBUF);
+    float* obuf = reinterpret_cast<float*>(sn_smem + SN_OFF_OBUF);
     const int t = threadIdx.x, c0 = blockIdx.x * SN_NC;
-    const int W = p.W, S = p.S, B = p.B, nq = W >> 2;
-    const int trow = t & (SN_R - 1);
-    int k_lo, k_hi;
-    sn_k_range(nq, &k_lo, &k_hi);
-    const f32x4* w0 = reinterpret_cast<const f32x4*>(p.Wt + (size_t)(c0 + 0) * W);
-    const f32x4* w1 = reinterpret_cast<const f32x4*>(p.Wt + (size_t)(c0 + 1) * W);
-    const f32x4* w2 = reinterpret_cast<const f32x4*>(p.Wt + (size_t)(c0 + 2) * W);
-    const f32x4* w3 = reinterpret_cast<const f32x4*>(p.Wt + (size_t)(c0 + 3) * W);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c0);
-    f32x4 z[RPT];
+    const int W = p.W, B = p.B, nq = W >> 2;
     SN_STAMP(0);
+    {
+        const int kp = t & 15;
+        float wr[2][4][4];
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const int r0 = j * SN_R;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (r0 < B) {  // uniform
-            sn_stage(tile, p.Hin + (size_t)r0 * W, min(SN_R, B - r0), W, S, p.step_row, p.step_col);
-            SN_STAMP(1 + 4 * j);
-            __syncthreads();
-            SN_STAMP(2 + 4 * j);
-            // every thread runs the loop (rows past the batch read stale LDS; their results are never used)
-            const float* hrow = tile + trow * S;
-#pragma unroll 2
-            for (int k4 = k_lo; k4 < k_hi; ++k4) {
-                const f32x4 h = *reinterpret_cast<const f32x4*>(hrow + 4 * k4);
-                const f32x4 x0 = w0[k4], x1 = w1[k4], x2 = w2[k4], x3 = w3[k4];
+        for (int s = 0; s < 2; ++s) {
+            const int k4 = kp + 16 * s;
+            const int k4c = min(k4, nq - 1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[0] = fmaf(h[e], x0[e], a[0]);
-                    a[1] = fmaf(h[e], x1[e], a[1]);
-                    a[2] = fmaf(h[e], x2[e], a[2]);
-                    a[3] = fmaf(h[e], x3[e], a[3]);
-                }
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.Wt + (size_t)(c0 + c) * W + 4 * k4c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wr[s][e][c] = k4 < nq ? v[e] : 0.f;
             }
-            SN_STAMP(3 + 4 * j);
-            a = sn_combine_parts(a, part);
-            SN_STAMP(4 + 4 * j);
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) z[j][c] = fmaxf(a[c] + bv[c], 0.f);
+        sn_rowdot(p.Hin, B, W, wr, obuf);
     }
-    const bool owner = t < SN_R;  // threads 0..255 own row j*256 + t of every chunk
-    float mu[4], sc[4];
+    SN_STAMP(1);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c0);
     const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c0);
     const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + c0);
     // running statistics are read BEFORE anything of this launch is stored: no load waits behind a store later
     const f32x4 rm = *reinterpret_cast<const f32x4*>(p.running_mean + c0);
     const f32x4 rv = *reinterpret_cast<const f32x4*>(p.running_var + c0);
+    f32x4 hin[RPT];
+    if (p.residual) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int r = j * SN_T + t;
+            if (r < B) hin[j] = *reinterpret_cast<const f32x4*>(p.Hin + (size_t)r * W + c0);
+        }
+    }
+    __syncthreads();
+    SN_STAMP(2);
+    f32x4 z[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int r = j * SN_T + t;
+        if (r < B) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(obuf + 4 * r);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) z[j][c] = fmaxf(a[c] + bv[c], 0.f);
+        }
+    }
+    float mu[4], sc[4];
     if (p.train) {
         double s[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            if (owner && j * SN_R + t < B) {
+            if (j * SN_T + t < B) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const double zd = (double)z[j][c];
@@ -225,7 +245,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_fwd_kernel(SnFwdP p) {
                 }
             }
         }
-        sn_block_sum<8>(s, red, reinterpret_cast<double*>(tile));
+        sn_block_sum<8>(s, red, xbuf);
         f32x4 o_mean, o_rstd, o_rm, o_rv;
         const double mom = (double)p.momentum;
 #pragma unroll
@@ -255,11 +275,10 @@ __global__ __launch_bounds__(SN_T) void sn_block_fwd_kernel(SnFwdP p) {
             sc[c] = gm[c] * (1.f / sqrtf(rv[c] + p.eps));
         }
     }
-    SN_STAMP(4 * RPT + 1);
-    if (!owner) return;
+    SN_STAMP(3);
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-        const int r = j * SN_R + t;
+        const int r = j * SN_T + t;
         if (r < B) {
             const size_t off = (size_t)r * W + c0;
             if (p.Z) *reinterpret_cast<f32x4*>(p.Z + off) = z[j];
@@ -267,18 +286,17 @@ __global__ __launch_bounds__(SN_T) void sn_block_fwd_kernel(SnFwdP p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = (z[j][c] - mu[c]) * sc[c] + bt[c];
             if (p.residual) {
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(p.Hin + off);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = hi[c] + o[c];
+                for (int c = 0; c < 4; ++c) o[c] = hin[j][c] + o[c];
             }
             *reinterpret_cast<f32x4*>(p.Hout + off) = o;
         }
     }
-    SN_STAMP(4 * RPT + 2);
+    SN_STAMP(4);
 }
 
 struct SnBwdP {
-    int B, W, S, O, step_row, step_col;
+    int B, W, O;
     int keep;             // 1: g += ...  (residual net below the deepest exit), 0: g = ...
     float* G;             // [B,W] running dL/dh, this workgroup's columns updated in place
     const float* dUprev;  // [B,W] dL/d(Linear output) of the deeper block, or NULL (deepest exit)
@@ -305,43 +323,36 @@ template <int RPT, bool HAS_BN, int VEC>
 __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
     extern __shared__ __attribute__((aligned(16))) char sn_smem[];
     double* red = reinterpret_cast<double*>(sn_smem);
-    float* part = reinterpret_cast<float*>(sn_smem + SN_OFF_PART);
-    float* dul = reinterpret_cast<float*>(sn_smem + SN_OFF_DUL);
-    float* tile = dul + (size_t)p.B * 4;
+    double* xbuf = reinterpret_cast<double*>(sn_smem + SN_OFF_XBUF);
+    float* rbuf = reinterpret_cast<float*>(sn_smem + SN_OFF_RBUF);
+    float* obuf = reinterpret_cast<float*>(sn_smem + SN_OFF_OBUF);  // dU W columns, then this block's dU columns
     const int t = threadIdx.x, c0 = blockIdx.x * SN_NC;
-    const int W = p.W, S = p.S, B = p.B, nq = W >> 2;
-    const int trow = t & (SN_R - 1);
-    const bool owner = t < SN_R;
-    int k_lo, k_hi;
-    sn_k_range(nq, &k_lo, &k_hi);
+    const int W = p.W, B = p.B, nq = W >> 2;
 
     // ---- 1. gradient w.r.t. this block's output, own columns -------------------------------------------------
-    f32x4 g[RPT];
+    if (p.dUprev) {  // uniform
+        const int kp = t & 15;
+        float wr[2][4][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k4 = kp + 16 * s;
+            const int k4c = min(k4, nq - 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.Wprev + (size_t)(4 * k4c + e) * W + c0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wr[s][e][c] = k4 < nq ? v[c] : 0.f;
+            }
+        }
+        sn_rowdot(p.dUprev, B, W, wr, obuf);
+    }
+    // operands of the elementwise phases: issued before the barrier
+    f32x4 g[RPT], z[RPT];
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-        const int r0 = j * SN_R;
+        const int r = j * SN_T + t;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (r0 < B && p.dUprev) {  // uniform
-            sn_stage(tile, p.dUprev + (size_t)r0 * W, min(SN_R, B - r0), W, S, p.step_row, p.step_col);
-            __syncthreads();
-            const float* urow = tile + trow * S;
-            const float* wcol = p.Wprev + c0;
-#pragma unroll 2
-            for (int k4 = k_lo; k4 < k_hi; ++k4) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>(urow + 4 * k4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(wcol + (size_t)(4 * k4 + e) * W);
-                    a[0] = fmaf(u[e], w[0], a[0]);
-                    a[1] = fmaf(u[e], w[1], a[1]);
-                    a[2] = fmaf(u[e], w[2], a[2]);
-                    a[3] = fmaf(u[e], w[3], a[3]);
-                }
-            }
-            a = sn_combine_parts(a, part);
-        }
-        const int r = r0 + t;
-        if (owner && r < B) {
+        if (r < B) {
             const size_t off = (size_t)r * W + c0;
             for (int o = 0; o < p.O; ++o) {
                 const float da = p.dact[(size_t)r * p.O + o];
@@ -354,9 +365,22 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) a[c] += old[c];
             }
-            *reinterpret_cast<f32x4*>(p.G + off) = a;
+            if (HAS_BN) z[j] = *reinterpret_cast<const f32x4*>(p.Z + off);
         }
         g[j] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int r = j * SN_T + t;
+        if (r < B) {
+            if (p.dUprev) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(obuf + 4 * r);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) g[j][c] += d[c];
+            }
+            *reinterpret_cast<f32x4*>(p.G + (size_t)r * W + c0) = g[j];
+        }
     }
 
     // ---- 2. BatchNorm + ReLU backward on own columns -> dU (global + LDS), dgamma, dbeta, db -------------------
@@ -369,72 +393,76 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
         for (int i = 0; i < 8; ++i) s[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const int r = j * SN_R + t;
-            if (owner && r < B) {
-                const f32x4 z = *reinterpret_cast<const f32x4*>(p.Z + (size_t)r * W + c0);
+            if (j * SN_T + t < B) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float xh = (z[c] - mu[c]) * rs[c];
+                    const float xh = (z[j][c] - mu[c]) * rs[c];
                     s[c] += (double)g[j][c];
                     s[4 + c] += (double)(g[j][c] * xh);
                 }
             }
         }
-        sn_block_sum<8>(s, red, reinterpret_cast<double*>(tile));
+        sn_block_sum<8>(s, red, xbuf);
         float mg[4], mgx[4];
+        f32x4 o_db, o_dg;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             mg[c] = (float)(s[c] / p.count);
             mgx[c] = (float)(s[4 + c] / p.count);
-            if (t == 0) {
-                p.dbeta[c0 + c] = (float)s[c];
-                p.dgamma[c0 + c] = (float)s[4 + c];
-            }
+            o_db[c] = (float)s[c];
+            o_dg[c] = (float)s[4 + c];
+        }
+        if (t == 0) {
+            *reinterpret_cast<f32x4*>(p.dbeta + c0) = o_db;
+            *reinterpret_cast<f32x4*>(p.dgamma + c0) = o_dg;
         }
         double sb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const int r = j * SN_R + t;
-            if (owner && r < B) {
-                const f32x4 z = *reinterpret_cast<const f32x4*>(p.Z + (size_t)r * W + c0);  // again: cache hit
+            const int r = j * SN_T + t;
+            if (r < B) {
                 f32x4 du;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float xh = (z[c] - mu[c]) * rs[c];
-                    du[c] = z[c] > 0.f ? (gm[c] * rs[c]) * (g[j][c] - mg[c] - xh * mgx[c]) : 0.f;
+                    const float xh = (z[j][c] - mu[c]) * rs[c];
+                    du[c] = z[j][c] > 0.f ? (gm[c] * rs[c]) * (g[j][c] - mg[c] - xh * mgx[c]) : 0.f;
                     sb[c] += (double)du[c];
                 }
                 *reinterpret_cast<f32x4*>(p.dU + (size_t)r * W + c0) = du;
-                *reinterpret_cast<f32x4*>(dul + 4 * r) = du;
+                *reinterpret_cast<f32x4*>(obuf + 4 * r) = du;  // same thread read this row's entry above
             }
         }
-        sn_block_sum<4>(sb, red, reinterpret_cast<double*>(tile));  // its barriers also publish dul
+        sn_block_sum<4>(sb, red, xbuf);  // its barriers also publish obuf
         if (t == 0) {
+            f32x4 o;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) p.dbias[c0 + c] = (float)sb[c];
+            for (int c = 0; c < 4; ++c) o[c] = (float)sb[c];
+            *reinterpret_cast<f32x4*>(p.dbias + c0) = o;
         }
     } else {
         double sb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const int r = j * SN_R + t;
-            if (owner && r < B) {
+            const int r = j * SN_T + t;
+            if (r < B) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) sb[c] += (double)g[j][c];
-                *reinterpret_cast<f32x4*>(dul + 4 * r) = g[j];
+                *reinterpret_cast<f32x4*>(obuf + 4 * r) = g[j];
             }
         }
-        sn_block_sum<4>(sb, red, reinterpret_cast<double*>(tile));
+        sn_block_sum<4>(sb, red, xbuf);
         if (t == 0) {
+            f32x4 o;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) p.dbias[c0 + c] = (float)sb[c];
+            for (int c = 0; c < 4; ++c) o[c] = (float)sb[c];
+            *reinterpret_cast<f32x4*>(p.dbias + c0) = o;
         }
     }
 
-    // ---- 3. dW[c0+c, k] = sum_r dU[r,c] A[r,k]: lanes across k, 32 row groups, shuffle + LDS combine ----------
+    // ---- 3. dW[c0+c, k] = sum_r dU[r,c] A[r,k]: lanes across k, 16 row groups, shuffle + LDS combine ----------
     constexpr int KW = 32 * VEC;  // k values per pass
+    constexpr int NRG = SN_T / 32;
     const int kq = t & 31, rg = t >> 5, wv = t >> 6;
-    float* rbuf = tile;  // [16 waves][4][KW]
     for (int kc = 0; kc < p.K; kc += KW) {
         const int k = kc + kq * VEC;
         float acc[4][VEC];
@@ -444,34 +472,28 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
             for (int e = 0; e < VEC; ++e) acc[c][e] = 0.f;
         if (k < p.K) {
             const float* ap = p.A + k;
-            for (int rb = rg; rb < B; rb += (SN_T / 32) * SN_DW_U) {
+            for (int rb = rg; rb < B; rb += NRG * SN_DW_U) {
                 float av[SN_DW_U][VEC];
 #pragma unroll
-                for (int u = 0; u < SN_DW_U; ++u) {
-                    const int r = rb + (SN_T / 32) * u;
-                    if (r < B) {
-                        if (VEC == 4) {
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + (size_t)r * p.lda);
+                for (int u = 0; u < SN_DW_U; ++u) {  // branch-free: rows past the batch re-read the last row, weight 0
+                    const int r = min(rb + NRG * u, B - 1);
+                    if (VEC == 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(ap + (size_t)r * p.lda);
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) av[u][e] = v[e];
-                        } else {
-                            av[u][0] = ap[(size_t)r * p.lda];
-                        }
+                        for (int e = 0; e < VEC; ++e) av[u][e] = v[e];
                     } else {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) av[u][e] = 0.f;
+                        av[u][0] = ap[(size_t)r * p.lda];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < SN_DW_U; ++u) {
-                    const int r = rb + (SN_T / 32) * u;
-                    if (r < B) {
-                        const f32x4 d = *reinterpret_cast<const f32x4*>(dul + 4 * r);
+                    const int r = rb + NRG * u;
+                    f32x4 d = *reinterpret_cast<const f32x4*>(obuf + 4 * min(r, B - 1));
+                    if (r >= B) d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
+                    for (int c = 0; c < 4; ++c)
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) acc[c][e] = fmaf(d[c], av[u][e], acc[c][e]);
-                    }
+                        for (int e = 0; e < VEC; ++e) acc[c][e] = fmaf(d[c], av[u][e], acc[c][e]);
                 }
             }
         }
@@ -488,7 +510,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
             if (kc + kk < p.K) {
                 float sum = 0.f;
 #pragma unroll
-                for (int gI = 0; gI < SN_T / 64; ++gI) sum += rbuf[(gI * 4 + c) * KW + kk];
+                for (int gI = 0; gI < SN_WAVES; ++gI) sum += rbuf[(gI * 4 + c) * KW + kk];
                 p.dW[(size_t)(c0 + c) * p.K + kc + kk] = sum;
             }
         }
@@ -501,7 +523,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
 // ---------------------------------------------------------------------------------------------------------
 static int sn_rpt(int B) {
     int r = 1;
-    while (r * SN_R < B) r <<= 1;
+    while (r * SN_T < B) r <<= 1;
     return r;
 }
 
@@ -525,7 +547,7 @@ static int sn_allow_lds(K kernel, size_t bytes) {
 
 template <int RPT>
 static int sn_launch_fwd(const SnFwdP& p, hipStream_t s) {
-    const size_t lds = sn_fwd_lds(p.W);
+    const size_t lds = sn_lds(p.B);
     int rc = sn_allow_lds(sn_block_fwd_kernel<RPT>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(sn_block_fwd_kernel<RPT>, dim3(p.W / SN_NC), dim3(SN_T), lds, s, p);
@@ -535,7 +557,7 @@ static int sn_launch_fwd(const SnFwdP& p, hipStream_t s) {
 
 template <int RPT, bool HAS_BN, int VEC>
 static int sn_launch_bwd(const SnBwdP& p, hipStream_t s) {
-    const size_t lds = sn_bwd_lds(p.B, p.W);
+    const size_t lds = sn_lds(p.B);
     int rc = sn_allow_lds(sn_block_bwd_kernel<RPT, HAS_BN, VEC>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((sn_block_bwd_kernel<RPT, HAS_BN, VEC>), dim3(p.W / SN_NC), dim3(SN_T), lds, s, p);
@@ -548,8 +570,7 @@ static int sn_dispatch_bwd(const SnBwdP& p, hipStream_t s) {
     switch (sn_rpt(p.B)) {
         case 1: return sn_launch_bwd<1, HAS_BN, VEC>(p, s);
         case 2: return sn_launch_bwd<2, HAS_BN, VEC>(p, s);
-        case 4: return sn_launch_bwd<4, HAS_BN, VEC>(p, s);
-        default: return sn_launch_bwd<8, HAS_BN, VEC>(p, s);
+        default: return sn_launch_bwd<4, HAS_BN, VEC>(p, s);
     }
 }
 
@@ -568,12 +589,6 @@ bool sn_eligible(const dun_fc_ctx* c, bool backward) {
     return ok;
 }
 
-static void sn_steps(int W, int* step_row, int* step_col) {
-    const int nq = W >> 2;
-    *step_row = SN_T / nq;
-    *step_col = SN_T % nq;
-}
-
 int sn_forward_block(const dun_fc_ctx* c, int i, hipStream_t s) {
     const int W = c->W, B = c->B;
     if (c->train) DUN_REQUIRE(B > 1, "dun_fc_forward: BatchNorm in train mode needs more than 1 row (got %d)", B);
@@ -590,14 +605,12 @@ int sn_forward_block(const dun_fc_ctx* c, int i, hipStream_t s) {
     p.rstd = c->train ? c->bn_rstd + (size_t)i * W : nullptr;
     p.running_mean = c->running_mean + (size_t)i * W;
     p.running_var = c->running_var + (size_t)i * W;
-    p.B = B; p.W = W; p.S = sn_stride(W); p.train = c->train; p.residual = c->residual;
-    sn_steps(W, &p.step_row, &p.step_col);
+    p.B = B; p.W = W; p.train = c->train; p.residual = c->residual;
     p.eps = c->bn_eps; p.momentum = c->bn_momentum; p.count = (double)B;
     switch (sn_rpt(B)) {
         case 1: return sn_launch_fwd<1>(p, s);
         case 2: return sn_launch_fwd<2>(p, s);
-        case 4: return sn_launch_fwd<4>(p, s);
-        default: return sn_launch_fwd<8>(p, s);
+        default: return sn_launch_fwd<4>(p, s);
     }
 }
 
@@ -609,8 +622,7 @@ int sn_backward_blocks(const dun_fc_ctx* c, float* dU2, hipStream_t s) {
     const float* prev = nullptr;
     for (int i = L - 1; i >= -1; --i) {
         memset(&p, 0, sizeof(p));
-        p.B = B; p.W = W; p.S = sn_stride(W); p.O = c->O;
-        sn_steps(W, &p.step_row, &p.step_col);
+        p.B = B; p.W = W; p.O = c->O;
         p.G = c->G;
         p.dUprev = prev;
         p.Wprev = prev ? c->p.w + (size_t)(i + 1) * W * W : nullptr;

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     SnFwdP p; memset(&p, 0, sizeof(p));
     p.Hin = H; p.Wt = Wt; p.bias = vec; p.gamma = vec + W; p.beta = vec + 2 * W; p.Z = Z; p.Hout = Hout;
     p.mean = st; p.rstd = st + W; p.running_mean = st + 2 * W; p.running_var = st + 3 * W;
-    p.B = B; p.W = W; p.S = sn_stride(W); p.train = 1; p.residual = 1; sn_steps(W, &p.step_row, &p.step_col);
+    p.B = B; p.W = W; p.train = 1; p.residual = 1;
     p.eps = 1e-5f; p.momentum = 0.1f; p.count = B; p.dbg = dbg;
     for (int it = 0; it < 3; ++it) {
         CK(hipMemset(dbg, 0, 64 * 8 * 32));
