@@ -30,7 +30,7 @@ constexpr int SN_NC = 4;          // columns owned by a workgroup
 constexpr int SN_MAX_B = 2048;
 constexpr int SN_MAX_W = 128;     // 16 lanes x 2 K steps x 4 floats
 constexpr int SN_U = 16;          // row groups (of 4 rows per wave) in flight per batch of loads: 512 rows at once
-constexpr int SN_DW_U = 8;        // rows in flight per thread in the dW phase
+constexpr int SN_DW_U = 32;       // rows in flight per thread in the dW phase (one batch up to 512 rows)
 
 // dynamic LDS carve (every offset a multiple of 16 bytes):
 //   [red: 8 doubles][xbuf: 8 x 512 doubles, block sums][rbuf: 8 waves x 4 x 128 floats, dW combine][obuf: B x 4 floats]
@@ -317,6 +317,9 @@ struct SnBwdP {
     const float* A;       // h_i [B,W] or x [B,din]
     int K, lda;
     float* dW;            // [W,K]
+#ifdef SN_PROFILE
+    long long* dbg;
+#endif
 };
 
 template <int RPT, bool HAS_BN, int VEC>
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
     const int W = p.W, B = p.B, nq = W >> 2;
 
     // ---- 1. gradient w.r.t. this block's output, own columns -------------------------------------------------
+    SN_STAMP(0);
     if (p.dUprev) {  // uniform
         const int kp = t & 15;
         float wr[2][4][4];
@@ -346,6 +350,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
         }
         sn_rowdot(p.dUprev, B, W, wr, obuf);
     }
+    SN_STAMP(1);
     // operands of the elementwise phases: issued before the barrier
     f32x4 g[RPT], z[RPT];
 #pragma unroll
@@ -383,7 +388,36 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
         }
     }
 
-    // ---- 2. BatchNorm + ReLU backward on own columns -> dU (global + LDS), dgamma, dbeta, db -------------------
+    // first batch of the weight-gradient operand (rows of A): issued here so that the loads fly under phase 2
+    constexpr int KW = 32 * VEC;  // k values per pass
+    constexpr int NRG = SN_T / 32;
+    const int kq = t & 31, rg = t >> 5, wv = t >> 6;
+    float av[SN_DW_U][VEC];
+    auto load_rows = [&](int k, int rb) {  // branch-free inside: rows past the batch re-read the last row (weight 0)
+        if (k < p.K) {
+            const float* ap = p.A + k;
+#pragma unroll
+            for (int u = 0; u < SN_DW_U; ++u) {
+                const int r = min(rb + NRG * u, B - 1);
+                if (VEC == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ap + (size_t)r * p.lda);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) av[u][e] = v[e];
+                } else {
+                    av[u][0] = ap[(size_t)r * p.lda];
+                }
+            }
+        } else {  // k == K: the column of ones that yields the bias gradient (lanes beyond it are never stored)
+#pragma unroll
+            for (int u = 0; u < SN_DW_U; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) av[u][e] = e == 0 ? 1.f : 0.f;
+        }
+    };
+    SN_STAMP(2);
+    load_rows(kq * VEC, rg);
+
+    // ---- 2. BatchNorm + ReLU backward on own columns -> dU (global + LDS), dgamma, dbeta ----------------------
     if (HAS_BN) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c0);
         const f32x4 rs = *reinterpret_cast<const f32x4*>(p.rstd + c0);
@@ -403,6 +437,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
             }
         }
         sn_block_sum<8>(s, red, xbuf);
+        SN_STAMP(3);
         float mg[4], mgx[4];
         f32x4 o_db, o_dg;
 #pragma unroll
@@ -416,7 +451,6 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
             *reinterpret_cast<f32x4*>(p.dbeta + c0) = o_db;
             *reinterpret_cast<f32x4*>(p.dgamma + c0) = o_dg;
         }
-        double sb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const int r = j * SN_T + t;
@@ -426,77 +460,46 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
                 for (int c = 0; c < 4; ++c) {
                     const float xh = (z[j][c] - mu[c]) * rs[c];
                     du[c] = z[j][c] > 0.f ? (gm[c] * rs[c]) * (g[j][c] - mg[c] - xh * mgx[c]) : 0.f;
-                    sb[c] += (double)du[c];
                 }
                 *reinterpret_cast<f32x4*>(p.dU + (size_t)r * W + c0) = du;
                 *reinterpret_cast<f32x4*>(obuf + 4 * r) = du;  // same thread read this row's entry above
             }
         }
-        sn_block_sum<4>(sb, red, xbuf);  // its barriers also publish obuf
-        if (t == 0) {
-            f32x4 o;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = (float)sb[c];
-            *reinterpret_cast<f32x4*>(p.dbias + c0) = o;
-        }
     } else {
-        double sb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const int r = j * SN_T + t;
-            if (r < B) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) sb[c] += (double)g[j][c];
-                *reinterpret_cast<f32x4*>(obuf + 4 * r) = g[j];
-            }
-        }
-        sn_block_sum<4>(sb, red, xbuf);
-        if (t == 0) {
-            f32x4 o;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = (float)sb[c];
-            *reinterpret_cast<f32x4*>(p.dbias + c0) = o;
+            if (r < B) *reinterpret_cast<f32x4*>(obuf + 4 * r) = g[j];
         }
     }
+    __syncthreads();  // obuf = this block's dU columns (or g for the input layer)
+    SN_STAMP(4);
 
-    // ---- 3. dW[c0+c, k] = sum_r dU[r,c] A[r,k]: lanes across k, 16 row groups, shuffle + LDS combine ----------
-    constexpr int KW = 32 * VEC;  // k values per pass
-    constexpr int NRG = SN_T / 32;
-    const int kq = t & 31, rg = t >> 5, wv = t >> 6;
-    for (int kc = 0; kc < p.K; kc += KW) {
+    // ---- 3. dW[c0+c, k] = sum_r dU[r,c] A[r,k] and db[c0+c] = sum_r dU[r,c] (a virtual column k = K of ones):
+    //         lanes across k, 16 row groups, shuffle + LDS combine -------------------------------------------------
+    bool have_first = true;
+    for (int kc = 0; kc <= p.K; kc += KW) {
         const int k = kc + kq * VEC;
         float acc[4][VEC];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[c][e] = 0.f;
-        if (k < p.K) {
-            const float* ap = p.A + k;
-            for (int rb = rg; rb < B; rb += NRG * SN_DW_U) {
-                float av[SN_DW_U][VEC];
+        for (int rb = rg; rb < B; rb += NRG * SN_DW_U) {
+            if (!have_first) load_rows(k, rb);
+            have_first = false;
 #pragma unroll
-                for (int u = 0; u < SN_DW_U; ++u) {  // branch-free: rows past the batch re-read the last row, weight 0
-                    const int r = min(rb + NRG * u, B - 1);
-                    if (VEC == 4) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(ap + (size_t)r * p.lda);
+            for (int u = 0; u < SN_DW_U; ++u) {
+                const int r = rb + NRG * u;
+                f32x4 d = *reinterpret_cast<const f32x4*>(obuf + 4 * min(r, B - 1));
+                if (r >= B) d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) av[u][e] = v[e];
-                    } else {
-                        av[u][0] = ap[(size_t)r * p.lda];
-                    }
-                }
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int u = 0; u < SN_DW_U; ++u) {
-                    const int r = rb + NRG * u;
-                    f32x4 d = *reinterpret_cast<const f32x4*>(obuf + 4 * min(r, B - 1));
-                    if (r >= B) d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc[c][e] = fmaf(d[c], av[u][e], acc[c][e]);
-                }
+                    for (int e = 0; e < VEC; ++e) acc[c][e] = fmaf(d[c], av[u][e], acc[c][e]);
             }
         }
+        SN_STAMP(5);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -507,15 +510,19 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
         __syncthreads();
         for (int idx = t; idx < 4 * KW; idx += SN_T) {
             const int c = idx / KW, kk = idx - c * KW;
-            if (kc + kk < p.K) {
+            if (kc + kk <= p.K) {
                 float sum = 0.f;
 #pragma unroll
                 for (int gI = 0; gI < SN_WAVES; ++gI) sum += rbuf[(gI * 4 + c) * KW + kk];
-                p.dW[(size_t)(c0 + c) * p.K + kc + kk] = sum;
+                if (kc + kk < p.K)
+                    p.dW[(size_t)(c0 + c) * p.K + kc + kk] = sum;
+                else
+                    p.dbias[c0 + c] = sum;
             }
         }
         __syncthreads();
     }
+    SN_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------

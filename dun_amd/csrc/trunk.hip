@@ -354,6 +354,19 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
+// the same update, element by element: tensors that are not 16-byte aligned (the q_logits / log_std gradients are
+// views into the objective's result block)
+__global__ __launch_bounds__(256) void sgd_scalar_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ buf, size_t n, float lr, float momentum,
+                                                         float wd) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float ge = g[i] + wd * p[i];
+        const float b = momentum * buf[i] + ge;
+        buf[i] = b;
+        p[i] -= lr * b;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------
@@ -670,8 +683,15 @@ extern "C" int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream) {
 extern "C" int dun_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum,
                             float weight_decay, dun_stream_t stream) {
     DUN_REQUIRE(p && g && buf, "dun_sgd_step: null pointer");
-    DUN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(buf), "dun_sgd_step: buffers must be 16-byte aligned");
     if (n == 0) return DUN_OK;
+    if (!(aligned16(p) && aligned16(g) && aligned16(buf))) {
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(sgd_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, p, g, buf, n, lr, momentum,
+                           weight_decay);
+        DUN_LAUNCH_CHECK();
+        return DUN_OK;
+    }
     const size_t n4 = n / 4;
     size_t blocks = (n4 + 255) / 256;
     if (blocks < 1) blocks = 1;

@@ -111,8 +111,8 @@ class HipBackend(object):
             L.stream_ptr(sums.device)), "dun_depth_finalize")
         return res
 
-    def predict(self, act, q, regression, get_std=False, y=None, log_std=None):
-        """Depth-marginal prediction; with y also the metric sums (double [2])."""
+    def predict(self, act, q, regression, get_std=False, y=None, log_std=None, metrics_out=None):
+        """Depth-marginal prediction; with y also the metric sums (double [2], written into `metrics_out` if given)."""
         lib = L.lib()
         dev = act.device
         D = act.shape[0]
@@ -127,7 +127,7 @@ class HipBackend(object):
             if y is not None:
                 nparts = lib.dun_predict_num_partials(n, 1)
                 partials = torch.empty(2, nparts, device=dev, dtype=torch.float64)
-                metrics = torch.empty(2, device=dev, dtype=torch.float64)
+                metrics = metrics_out if metrics_out is not None else torch.empty(2, device=dev, dtype=torch.float64)
             L.check(lib.dun_predict_gauss(L.f32(act), L.f32(q), D, n, L.f32(mean), None if std is None else L.f32(std),
                                           None if y is None else L.f32(y), None if y is None else L.f32(log_std),
                                           None if partials is None else L.ptr(partials),
@@ -139,7 +139,7 @@ class HipBackend(object):
         if y is not None:
             nparts = lib.dun_predict_num_partials(B, max(Cn, 2))
             partials = torch.empty(2, nparts, device=dev, dtype=torch.float64)
-            metrics = torch.empty(2, device=dev, dtype=torch.float64)
+            metrics = metrics_out if metrics_out is not None else torch.empty(2, device=dev, dtype=torch.float64)
         L.check(lib.dun_predict_softmax(L.f32(act), L.f32(q), D, B, Cn, L.f32(probs), None if y is None else L.ptr(y),
                                         None if partials is None else L.ptr(partials),
                                         None if metrics is None else L.ptr(metrics), s), "dun_predict_softmax")

@@ -78,11 +78,13 @@ class DUN(BaseNet):
             roots.append(-prior_term / self.N_train)
             grads.append(None)
         torch.autograd.backward(roots, grads)
+        # the gradients of q_logits / log_std are views into this step's result block (a fresh tensor per eager step,
+        # the static one of a captured step): no copy launches
         q_logits = getattr(self.prob_model, "q_logits", None)
         if q_logits is not None and q_logits.requires_grad:
-            q_logits.grad = out.dq_logits.clone()
+            q_logits.grad = out.dq_logits
         if self.regression and self.f_neg_loglike.log_std.requires_grad:
-            self.f_neg_loglike.log_std.grad = out.dlog_std.clone().reshape(self.f_neg_loglike.log_std.shape)
+            self.f_neg_loglike.log_std.grad = out.dlog_std.reshape(self.f_neg_loglike.log_std.shape)
         if self._dist is not None:
             self._reduce_loose_gradients()
             self._dist.wait_gradients()
@@ -102,19 +104,22 @@ class DUN(BaseNet):
         be = kernels.backend()
         act = act_vec.detach()
         post = self.prob_model.current_posterior
+        # [objective,] nll_sum, err_sum in ONE fp64 tensor: the kernel writes its two sums straight into it
+        out = torch.empty(3 if objective is not None else 2, device=act.device, dtype=torch.float64)
+        m = out[-2:]
         if self.regression:
-            _, _, m = be.predict(act, post, True, get_std=True, y=y.to(torch.float32).contiguous(),
-                                 log_std=self.f_neg_loglike.log_std.detach())
+            be.predict(act, post, True, get_std=True, y=y.to(torch.float32).contiguous(),
+                       log_std=self.f_neg_loglike.log_std.detach(), metrics_out=m)
             n = act[0].numel()
         else:
-            _, _, m = be.predict(act, post, False, y=y.contiguous())
+            be.predict(act, post, False, y=y.contiguous(), metrics_out=m)
             n = act.shape[1]
         if self._dist is not None:
             self._dist.all_reduce(m)
             n = self._dist.global_batch(n)
         if objective is not None:
-            m = torch.cat([objective.detach().reshape(1).double(), m])
-        return m, n
+            out[0:1].copy_(objective.detach().reshape(1))  # float -> double inside the copy
+        return out, n
 
     def _metrics_host(self, m, n):
         """ONE device->host copy for everything fit / eval return."""
@@ -182,10 +187,17 @@ class DUN(BaseNet):
         graph.replay()
         return self._metrics_host(m, n)
 
+    def _prior_loglikes(self):
+        """model.get_w_prior_loglike(k=None); None (= the zeros the reference returns, src/DUN/stochastic_fc_models.py:52)
+        when the model declares no weight prior, which saves the fill launch of a fresh zeros tensor per step."""
+        if getattr(self.model, "w_prior", 0) is None:
+            return None
+        return self.model.get_w_prior_loglike(k=None)
+
     def _step(self, x, y):
         self.optimizer.zero_grad()
         act_vec = self.model.forward(x)
-        prior_loglikes = self.model.get_w_prior_loglike(k=None)
+        prior_loglikes = self._prior_loglikes()
         out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train)
         self._backward(act_vec, prior_loglikes, out)
         self.optimizer.step()
@@ -303,7 +315,7 @@ class DUN_VI(DUN):
     def _step(self, x, y):
         self.optimizer.zero_grad()
         act_vec = self.model.forward(x)
-        prior_loglikes = self.model.get_w_prior_loglike(k=None)
+        prior_loglikes = self._prior_loglikes()
         out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train, Beta=1)
         self._backward(act_vec, prior_loglikes, out)
         self.optimizer.step()

@@ -35,5 +35,28 @@ int main(int argc, char** argv) {
             printf("  ns (total %lld)\n", (hb[blk * 32 + 31] ? 0 : 0) + 0LL);
         }
     }
+    // backward kernel of one block (deeper block's dU and weights present)
+    float *G, *dUp, *dU, *dact, *gr, *dW;
+    CK(hipMalloc(&G, (size_t)B * W * 4)); CK(hipMalloc(&dUp, (size_t)B * W * 4)); CK(hipMalloc(&dU, (size_t)B * W * 4));
+    CK(hipMalloc(&dact, (size_t)B * 4)); CK(hipMalloc(&gr, 8 * W * 4)); CK(hipMalloc(&dW, (size_t)W * W * 4));
+    CK(hipMemcpy(G, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dUp, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dact, h.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    SnBwdP q; memset(&q, 0, sizeof(q));
+    q.B = B; q.W = W; q.O = 1; q.keep = 1; q.G = G; q.dUprev = dUp; q.Wprev = Wt; q.dact = dact; q.w_out = vec;
+    q.Z = Z; q.mean = st; q.rstd = st + W; q.gamma = vec + W; q.dgamma = gr; q.dbeta = gr + W; q.dbias = gr + 2 * W;
+    q.dU = dU; q.count = B; q.A = H; q.K = W; q.lda = W; q.dW = dW; q.dbg = dbg;
+    for (int it = 0; it < 3; ++it) {
+        CK(hipMemset(dbg, 0, 64 * 8 * 32));
+        if (sn_dispatch_bwd<true, 4>(q, 0)) { printf("launch failed\n"); return 1; }
+        CK(hipDeviceSynchronize());
+        long long hb[64 * 32];
+        CK(hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost));
+        for (int blk = 0; blk < 25 && blk < W / 4; blk += 12) {
+            printf("bwd it %d block %2d:", it, blk);
+            for (int i = 1; i < 32 && hb[blk * 32 + i]; ++i) printf(" %lld", (hb[blk * 32 + i] - hb[blk * 32 + i - 1]) * 10);
+            printf("  ns\n");
+        }
+    }
     return 0;
 }

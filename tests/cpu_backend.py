@@ -107,7 +107,7 @@ class CpuBackend(object):
             res[H_ + k * D:H_ + (k + 1) * D] = v.float()
         return res
 
-    def predict(self, act, q, regression, get_std=False, y=None, log_std=None):
+    def predict(self, act, q, regression, get_std=False, y=None, log_std=None, metrics_out=None):
         q = q.detach().float()
         qb = q.view(-1, *([1] * (act.dim() - 1)))
         if regression:
@@ -119,6 +119,8 @@ class CpuBackend(object):
                 st = (sig ** 2 + std ** 2) ** 0.5
                 nll = 0.5 * math.log(2 * math.pi) + torch.log(st) + (y - mu) ** 2 / (2 * st ** 2)
                 metrics = torch.stack([nll.double().sum(), ((mu - y).double() ** 2).sum()])
+                if metrics_out is not None:
+                    metrics = metrics_out.copy_(metrics)
             return mu, (std if (get_std or y is not None) else None), metrics
         probs = (qb * F.softmax(act, dim=2)).sum(0)
         metrics = None
@@ -126,6 +128,8 @@ class CpuBackend(object):
             nll = -torch.log(probs.gather(1, y.view(-1, 1))).double().sum()
             err = probs.max(dim=1)[1].ne(y).double().sum()
             metrics = torch.stack([nll, err])
+            if metrics_out is not None:
+                metrics = metrics_out.copy_(metrics)
         return probs, None, metrics
 
     # ---- trunk, staged exactly like the C entries ----
