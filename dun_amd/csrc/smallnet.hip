@@ -24,13 +24,28 @@
 
 namespace dun {
 
-constexpr int SN_T = 512;         // threads per workgroup: 8 waves, two per SIMD (256 VGPRs each)
+// tunables (-D overrides are for A/B builds; measured on the UCI shape, forward / backward of 10 blocks in us:
+// 512 threads, 16 groups in flight 101 / 174; 512, 8: 97.5 / 171 (default); 1024, 8: 105 / 163; 256, 16: 116 / 210;
+// prefetching the dW operand rows above the BatchNorm phase: +5 us backward)
+#ifndef SN_T_VALUE
+#define SN_T_VALUE 512
+#endif
+#ifndef SN_U_VALUE
+#define SN_U_VALUE 8
+#endif
+#ifndef SN_DW_U_VALUE
+#define SN_DW_U_VALUE 16
+#endif
+#ifndef SN_PREFETCH
+#define SN_PREFETCH 0
+#endif
+constexpr int SN_T = SN_T_VALUE;  // threads per workgroup: 8 waves, two per SIMD
 constexpr int SN_WAVES = SN_T / 64;
 constexpr int SN_NC = 4;          // columns owned by a workgroup
 constexpr int SN_MAX_B = 2048;
 constexpr int SN_MAX_W = 128;     // 16 lanes x 2 K steps x 4 floats
-constexpr int SN_U = 16;          // row groups (of 4 rows per wave) in flight per batch of loads: 512 rows at once
-constexpr int SN_DW_U = 32;       // rows in flight per thread in the dW phase (one batch up to 512 rows)
+constexpr int SN_U = SN_U_VALUE;    // row groups (4 rows per wave each) in flight per batch of loads
+constexpr int SN_DW_U = SN_DW_U_VALUE;  // rows in flight per thread in the dW phase
 
 // dynamic LDS carve (every offset a multiple of 16 bytes):
 //   [red: 8 doubles][xbuf: 8 x 512 doubles, block sums][rbuf: 8 waves x 4 x 128 floats, dW combine][obuf: B x 4 floats]
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
         }
     }
 
-    // first batch of the weight-gradient operand (rows of A): issued here so that the loads fly under phase 2
+    // rows of the weight-gradient operand A (SN_PREFETCH: first batch issued above phase 2 -- measured slower, off)
     constexpr int KW = 32 * VEC;  // k values per pass
     constexpr int NRG = SN_T / 32;
     const int kq = t & 31, rg = t >> 5, wv = t >> 6;
@@ -415,7 +430,9 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
         }
     };
     SN_STAMP(2);
+#if SN_PREFETCH
     load_rows(kq * VEC, rg);
+#endif
 
     // ---- 2. BatchNorm + ReLU backward on own columns -> dU (global + LDS), dgamma, dbeta ----------------------
     if (HAS_BN) {
@@ -477,7 +494,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
 
     // ---- 3. dW[c0+c, k] = sum_r dU[r,c] A[r,k] and db[c0+c] = sum_r dU[r,c] (a virtual column k = K of ones):
     //         lanes across k, 16 row groups, shuffle + LDS combine -------------------------------------------------
-    bool have_first = true;
+    bool have_first = SN_PREFETCH != 0;
     for (int kc = 0; kc <= p.K; kc += KW) {
         const int k = kc + kq * VEC;
         float acc[4][VEC];

@@ -117,6 +117,8 @@ class arq_uncert_fc_resnet(nn.Module):
         self.flat_params, self.flat_grads = flat, gflat
         self.running_mean, self.running_var, self.num_batches_tracked = rm, rv, nbt
         self._fc_cache = {}
+        # every parameter of the module tree lives in the flat buffer (what the whole-step hipGraph relies on)
+        self._all_params_flat = all(getattr(q, "_dun_flat_owner", None) is self for q in self.parameters())
 
     def _apply(self, fn, *args, **kwargs):
         super(arq_uncert_fc_resnet, self)._apply(fn, *args, **kwargs)
@@ -133,6 +135,7 @@ class arq_uncert_fc_resnet(nn.Module):
         st = self.__dict__.copy()
         st["_fc_cache"] = {}
         st["_dist"] = None
+        st.pop("_mode_synced", None)
         for k in ("stacked", "stacked_grad", "_param_list", "_grad_views", "flat_params", "flat_grads",
                   "running_mean", "running_var", "num_batches_tracked"):
             st.pop(k, None)
@@ -141,6 +144,17 @@ class arq_uncert_fc_resnet(nn.Module):
     def __setstate__(self, st):
         super(arq_uncert_fc_resnet, self).__setstate__(st)
         self._flatten()
+
+    def train(self, mode=True):
+        """nn.Module.train walks the ~30 sub-modules (tens of microseconds per call, and fit / eval / predict call it
+        every step like the reference does): skipped when the tree is already in that mode.  The kernels only read
+        this module's own flag; the children's flags matter to the torch cold path (vec_forward) and are kept in
+        step as long as modes are switched through this module, which is what the wrappers do."""
+        if self.training == mode and self.__dict__.get("_mode_synced") == mode:
+            return self
+        super(arq_uncert_fc_resnet, self).train(mode)
+        self.__dict__["_mode_synced"] = mode
+        return self
 
     # ---- weight priors: O(#params) torch reductions, not part of the per-sample path (SURVEY 8 a5) ----
     def apply_prior(self, module, prior_f):

@@ -150,8 +150,7 @@ class DUN(BaseNet):
         model = self.model
         if getattr(model, "flat_params", None) is None or getattr(model, "w_prior", None) is not None:
             return None
-        if not (x.is_cuda and y.is_cuda) or any(getattr(p, "_dun_flat_owner", None) is None
-                                                  for p in model.parameters()):
+        if not (x.is_cuda and y.is_cuda) or not getattr(model, "_all_params_flat", False):
             return None
         if 6.0 * x.shape[0] * model.flat_params.numel() > self.graph_max_flop:
             return None  # GPU-bound step: launches already hide under the kernels, nothing to gain
