@@ -955,7 +955,8 @@ extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n,
     DUN_REQUIRE(metrics == nullptr || (y && log_std && partials), "dun_predict_gauss: metrics need y, log_std, partials");
     const int nparts = dun_predict_num_partials(n, 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    double* part = metrics ? partials : nullptr;
+    // one workgroup: its [2][1] partials ARE the metric sums, no reduction launch
+    double* part = metrics ? (nparts == 1 ? metrics : partials) : nullptr;
     const bool vec = (n % 4 == 0) && aligned16(act);
     if (vec)
         hipLaunchKernelGGL(predict_gauss_kernel<true>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
@@ -964,7 +965,7 @@ extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n,
         hipLaunchKernelGGL(predict_gauss_kernel<false>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
                            log_std, part, nparts);
     DUN_LAUNCH_CHECK();
-    if (metrics) {
+    if (metrics && nparts > 1) {
         hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);
         DUN_LAUNCH_CHECK();
     }
@@ -984,7 +985,7 @@ extern "C" int dun_predict_softmax(const float* act, const float* q, int D, int 
     const int G = softmax_group(C, &km);
     const int nparts = dun_predict_num_partials(B, C > 1 ? C : 2);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    double* part = metrics ? partials : nullptr;
+    double* part = metrics ? (nparts == 1 ? metrics : partials) : nullptr;
     const bool lds_ok = ((long long)B * C) % 4 == 0 && aligned16(act) && aligned16(probs);
     if (lds_ok) {
         int g = 1;
@@ -1006,7 +1007,7 @@ extern "C" int dun_predict_softmax(const float* act, const float* q, int D, int 
         DUN_SOFTMAX_DISPATCH(predict_softmax_kernel, G, km, dim3(nparts), s, act, q, D, B, C, probs, y, part, nparts);
     }
     DUN_LAUNCH_CHECK();
-    if (metrics) {
+    if (metrics && nparts > 1) {
         hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);
         DUN_LAUNCH_CHECK();
     }

@@ -213,6 +213,25 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     if (ty == 0 && c < n) out[c] = (float)((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
 }
 
+// the weight- and bias-gradient partials in ONE launch: workgroups [0, nb_w) reduce dw, the rest db (same arithmetic)
+__global__ __launch_bounds__(256) void head_reduce2_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b,
+                                                           int P, size_t n_w, size_t n_b, int nb_w,
+                                                           float* __restrict__ out_w, float* __restrict__ out_b) {
+    __shared__ double red[HRY][HCX];
+    const int tx = threadIdx.x & (HCX - 1), ty = threadIdx.x >> 6;
+    const bool is_w = (int)blockIdx.x < nb_w;
+    const float* partials = is_w ? part_w : part_b;
+    const size_t n = is_w ? n_w : n_b;
+    float* out = is_w ? out_w : out_b;
+    const size_t c = (size_t)(is_w ? blockIdx.x : blockIdx.x - nb_w) * HCX + tx;
+    double s = 0.0;
+    if (c < n)
+        for (int p = ty; p < P; p += HRY) s += (double)partials[(size_t)p * n + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < n) out[c] = (float)((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+}
+
 static int pick_oc(int O) {
     if (O <= 1) return 1;
     if (O <= 2) return 2;
@@ -300,10 +319,9 @@ int head_backward(const float* H, const float* w, const float* dact, int rows, i
         DUN_LAUNCH_CHECK();
     }
     const size_t n = (size_t)O * K;
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((n + HCX - 1) / HCX)), dim3(256), 0, s, part_dw, nslab, n, dw);
-    DUN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((O + HCX - 1) / HCX)), dim3(256), 0, s, part_db, nslab,
-                       (size_t)O, db);
+    const int nb_w = (int)((n + HCX - 1) / HCX), nb_b = (O + HCX - 1) / HCX;
+    hipLaunchKernelGGL(head_reduce2_kernel, dim3((unsigned)(nb_w + nb_b)), dim3(256), 0, s, part_dw, part_db, nslab, n,
+                       (size_t)O, nb_w, dw, db);
     DUN_LAUNCH_CHECK();
     return DUN_OK;
 }

@@ -23,10 +23,10 @@ int head_backward(const float* H, const float* w, const float* dact, int rows, i
 size_t head_backward_ws(int rows, int K, int O);
 // smallnet.hip: one launch per block for widths <= 128 (toy / UCI configurations)
 bool sn_shape_ok(int B, int W);
-size_t sn_extra_ws_floats(int B, int W);
+size_t sn_extra_ws_floats(int B, int W, int L);
 bool sn_eligible(const dun_fc_ctx* c, bool backward);
 int sn_forward_block(const dun_fc_ctx* c, int i, hipStream_t s);
-int sn_backward_blocks(const dun_fc_ctx* c, float* dU2, hipStream_t s);
+int sn_backward_blocks(const dun_fc_ctx* c, float* dUall, hipStream_t s);
 
 // rows per column-reduction partial: 128, or 32 for small batches (four times the workgroups, a quarter of the serial
 // row loop: the UCI-sized nets are latency bound)
@@ -605,7 +605,7 @@ static size_t base_workspace_floats(int B, int W, int O, int L) {
 
 extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
     (void)din;
-    return base_workspace_floats(B, W, O, L) + sn_extra_ws_floats(B, W);
+    return base_workspace_floats(B, W, O, L) + sn_extra_ws_floats(B, W, L);
 }
 
 #define STREAM static_cast<hipStream_t>(stream)

@@ -96,8 +96,11 @@ class HipBackend(object):
             L.check(lib.dun_ll_softmax(L.f32(act), L.ptr(y), None if w is None else L.f32(w), int(w_is_logits), D, B,
                                        Cn, float(inv_batch), None if dact is None else L.f32(dact),
                                        None if ll is None else L.f32(ll), L.ptr(partials), s), "dun_ll_softmax")
-        sums = torch.empty(D, device=dev, dtype=torch.float64)
-        L.check(lib.dun_ll_reduce(L.ptr(partials), D, nparts, L.ptr(sums), s), "dun_ll_reduce")
+        if nparts == 1:
+            sums = partials.view(D)  # one workgroup per depth: its partial is the sum, no reduction launch
+        else:
+            sums = torch.empty(D, device=dev, dtype=torch.float64)
+            L.check(lib.dun_ll_reduce(L.ptr(partials), D, nparts, L.ptr(sums), s), "dun_ll_reduce")
         return sums, dact, ll
 
     def depth_finalize(self, sums, gaussian, q_logits, logprior, prior_ll, log_std, N_train, batch, beta, eps,

@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
     q.dU = dU; q.count = B; q.A = H; q.K = W; q.lda = W; q.dW = dW; q.dbg = dbg;
     for (int it = 0; it < 3; ++it) {
         CK(hipMemset(dbg, 0, 64 * 8 * 32));
-        if (sn_dispatch_bwd<true, 4>(q, 0)) { printf("launch failed\n"); return 1; }
+        if (sn_dispatch_bwd<true, 4, true>(q, 0)) { printf("launch failed\n"); return 1; }
         CK(hipDeviceSynchronize());
         long long hb[64 * 32];
         CK(hipMemcpy(hb, dbg, sizeof(hb), hipMemcpyDeviceToHost));
