@@ -170,6 +170,9 @@ typedef struct dun_fc_ctx {
 
 size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L);
 
+/* Whole net in one call.  W <= 128 (W % 4 == 0) with B <= 2048 -- the toy / UCI nets of experiments/toy/train_toy.py
+ * and experiments/regression -- run one column-owned launch per block (smallnet.hip) instead of the tiled GEMM
+ * sequence; DUN_SMALLNET=0 in the environment selects the tiled path.  Results agree to fp32 rounding. */
 int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream);  /* whole net, BatchNorm over the local batch */
 int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream); /* whole net, needs a train-mode forward */
 
@@ -201,7 +204,7 @@ int dun_head_backward(const float* H, const float* w, const float* dact, int row
 /* ------------------------------------------------------------------------------------------------------
  * torch.optim.SGD(momentum, weight_decay) over one flat parameter buffer, as configured at
  * src/DUN/training_wrappers.py:48-52: g += wd*p; buf = momentum*buf + g (buf = g on the first step, which a
- * zero-initialised buf reproduces); p -= lr*buf.
+ * zero-initialised buf reproduces); p -= lr*buf.  Any alignment (16-byte aligned buffers take the vector kernel).
  * ---------------------------------------------------------------------------------------------------- */
 int dun_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
                  dun_stream_t stream);
