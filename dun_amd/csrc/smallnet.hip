@@ -94,7 +94,7 @@ __device__ __forceinline__ void sn_row16_sum4(f32x4& a) {
 // sum of one value set per thread over the workgroup; every thread gets the totals.  The values go through LDS
 // transposed ([NV][512] doubles) so that only NV waves shuffle, one double each (waves butterflying NV doubles
 // apiece keep the LDS crossbar busy for microseconds).
-template <int NV>
+template <int NV, bool TRAILING_BARRIER = false>  // the trailing barrier is only needed if red / xbuf are written again
 __device__ __forceinline__ void sn_block_sum(double (&v)[NV], double* red, double* xbuf) {
     const int t = threadIdx.x;
 #pragma unroll
@@ -112,7 +112,7 @@ __device__ __forceinline__ void sn_block_sum(double (&v)[NV], double* red, doubl
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = red[i];
-    __syncthreads();
+    if (TRAILING_BARRIER) __syncthreads();
 }
 
 // obuf[r][c] = sum_k A[r,k] wk[k][c] for all rows r < B, c < 4: lane (r4 = lane>>4, kp = lane&15) of wave w covers
@@ -180,7 +180,7 @@ struct SnFwdP {
     float* running_var;
     int B, W, train, residual;
     float eps, momentum;
-    double count;
+    double count, inv_count, unbias;  // rows, 1/rows, rows/(rows-1)
 #ifdef SN_PROFILE
     long long* dbg;  // scripts/dev/sn_phase_probe.hip: [workgroup][32] clock stamps (10 ns units)
 #endif
@@ -265,11 +265,11 @@ __global__ __launch_bounds__(SN_T) void sn_block_fwd_kernel(SnFwdP p) {
         const double mom = (double)p.momentum;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const double m = s[c] / p.count;
-            double var = s[4 + c] / p.count - m * m;
+            const double m = s[c] * p.inv_count;
+            double var = s[4 + c] * p.inv_count - m * m;
             var = var > 0.0 ? var : 0.0;
             const double rs = 1.0 / sqrt(var + (double)p.eps);
-            const double unbiased = var * (p.count / (p.count - 1.0));
+            const double unbiased = var * p.unbias;
             mu[c] = (float)m;
             sc[c] = gm[c] * (float)rs;
             o_mean[c] = (float)m;
@@ -400,7 +400,7 @@ struct SnBwdP {
     float* dbeta;
     float* dbias;         // [W]: db_i (HAS_BN) or db_in
     float* dU;            // [B,W] out (HAS_BN)
-    double count;
+    double count, inv_count;
     // weight gradient: dW[c,k] = sum_r dU[r,c] A[r,k]
     const float* A;       // h_i [B,W] or x [B,din]
     int K, lda;
@@ -501,8 +501,8 @@ __global__ __launch_bounds__(SN_T) void sn_block_bwd_kernel(SnBwdP p) {
         f32x4 o_db, o_dg;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            mg[c] = (float)(s[c] / p.count);
-            mgx[c] = (float)(s[4 + c] / p.count);
+            mg[c] = (float)(s[c] * p.inv_count);
+            mgx[c] = (float)(s[4 + c] * p.inv_count);
             o_db[c] = (float)s[c];
             o_dg[c] = (float)s[4 + c];
         }
@@ -651,6 +651,7 @@ int sn_forward_block(const dun_fc_ctx* c, int i, hipStream_t s) {
     p.running_var = c->running_var + (size_t)i * W;
     p.B = B; p.W = W; p.train = c->train; p.residual = c->residual;
     p.eps = c->bn_eps; p.momentum = c->bn_momentum; p.count = (double)B;
+    p.inv_count = 1.0 / (double)B; p.unbias = B > 1 ? (double)B / ((double)B - 1.0) : 1.0;
     switch (sn_rpt(B)) {
         case 1: return sn_launch_fwd<1>(p, s);
         case 2: return sn_launch_fwd<2>(p, s);
@@ -675,7 +676,7 @@ int sn_backward_blocks(const dun_fc_ctx* c, float* dUall, hipStream_t s) {
         p.keep = (c->residual && prev) ? 1 : 0;
         p.dact = c->dact + (size_t)(i + 1) * B * c->O;
         p.w_out = c->p.w_out;
-        p.count = (double)B;
+        p.count = (double)B; p.inv_count = 1.0 / (double)B;
         int rc;
         if (i >= 0) {
             float* cur = dUall + (size_t)i * plane;

@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     p.Hin = H; p.Wt = Wt; p.bias = vec; p.gamma = vec + W; p.beta = vec + 2 * W; p.Z = Z; p.Hout = Hout;
     p.mean = st; p.rstd = st + W; p.running_mean = st + 2 * W; p.running_var = st + 3 * W;
     p.B = B; p.W = W; p.train = 1; p.residual = 1;
-    p.eps = 1e-5f; p.momentum = 0.1f; p.count = B; p.dbg = dbg;
+    p.eps = 1e-5f; p.momentum = 0.1f; p.count = B; p.inv_count = 1.0 / B; p.unbias = (double)B / (B - 1.0); p.dbg = dbg;
     for (int it = 0; it < 3; ++it) {
         CK(hipMemset(dbg, 0, 64 * 8 * 32));
         int rc = sn_rpt(B) == 1 ? sn_launch_fwd<1>(p, 0) : sn_rpt(B) == 2 ? sn_launch_fwd<2>(p, 0) : sn_launch_fwd<4>(p, 0);
@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     SnBwdP q; memset(&q, 0, sizeof(q));
     q.B = B; q.W = W; q.O = 1; q.keep = 1; q.G = G; q.dUprev = dUp; q.Wprev = Wt; q.dact = dact; q.w_out = vec;
     q.Z = Z; q.mean = st; q.rstd = st + W; q.gamma = vec + W; q.dgamma = gr; q.dbeta = gr + W; q.dbias = gr + 2 * W;
-    q.dU = dU; q.count = B; q.A = H; q.K = W; q.lda = W; q.dW = dW; q.dbg = dbg;
+    q.dU = dU; q.count = B; q.inv_count = 1.0 / B; q.A = H; q.K = W; q.lda = W; q.dW = dW; q.dbg = dbg;
     for (int it = 0; it < 3; ++it) {
         CK(hipMemset(dbg, 0, 64 * 8 * 32));
         if (sn_dispatch_bwd<true, 4, true>(q, 0)) { printf("launch failed\n"); return 1; }
