@@ -36,7 +36,7 @@ __device__ __forceinline__ float depth_weight(const float* __restrict__ w, int w
     return expf(w[d] - mx) / *sh;
 }
 
-template <bool VEC>
+template <bool VEC, bool NT = false>
 __global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__ act, const float* __restrict__ y,
                                                        const float* __restrict__ log_std,
                                                        const float* __restrict__ w, int w_is_logits, int D, int B,
@@ -61,11 +61,11 @@ __global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__
         const int idx = base + (it * 256 + tid) * 4;
         if (VEC) {
             if (idx < B) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(a_row + idx);
+                const f32x4 a = ld4_stream<NT>(a_row + idx);
                 const f32x4 t = *reinterpret_cast<const f32x4*>(y + idx);
                 f32x4 r = t - a;
                 acc += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
-                if (g_row) *reinterpret_cast<f32x4*>(g_row + idx) = coef * r;
+                if (g_row) st4_stream<NT>(g_row + idx, coef * r);
                 if (l_row) {
                     f32x4 o;
 #pragma unroll
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__
 // single barrier at the end instead of two per depth.  Same partial layout, same summation tree per depth.
 constexpr int GAUSS_DGROUP_MAX = 64;
 
+template <bool NT>
 __global__ __launch_bounds__(256) void ll_gauss_depths_kernel(const float* __restrict__ act, const float* __restrict__ y,
                                                               const float* __restrict__ log_std,
                                                               const float* __restrict__ w, int w_is_logits, int D,
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void ll_gauss_depths_kernel(const float* __res
         for (int it = 0; it < 4; ++it) {
             const int idx = base + it * 1024;
             a[it] = t[it];  // zero residual outside the batch
-            if (idx < B) a[it] = *reinterpret_cast<const f32x4*>(a_row + idx);
+            if (idx < B) a[it] = ld4_stream<NT>(a_row + idx);
         }
         float acc = 0.f;
 #pragma unroll
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void ll_gauss_depths_kernel(const float* __res
             const f32x4 r = t[it] - a[it];
             acc += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
             if (idx < B) {
-                if (dact) *reinterpret_cast<f32x4*>(dact + (size_t)d * B + idx) = coef * r;
+                if (dact) st4_stream<NT>(dact + (size_t)d * B + idx, coef * r);
                 if (ll) {
                     f32x4 o;
 #pragma unroll
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
                                                                    const float* __restrict__ w, int w_is_logits, int D,
                                                                    int B, int C, float inv_batch,
                                                                    float* __restrict__ dact, float* __restrict__ ll,
-                                                                   double* __restrict__ partials, int nparts) {
+                                                                   double* __restrict__ partials, int nparts, int nt) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ double red[4];
     __shared__ float sh_w;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
     const float* src = act + off;
     for (int i = tid * 4; i < nfl; i += 1024) {
         if (i + 3 < nfl) {
-            *reinterpret_cast<f32x4*>(tile + i) = *reinterpret_cast<const f32x4*>(src + i);
+            *reinterpret_cast<f32x4*>(tile + i) = ld4_stream(src + i, nt);
         } else {
             for (int e = i; e < nfl; ++e) tile[e] = src[e];
         }
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
         float* dst = dact + off;
         for (int i = tid * 4; i < nfl; i += 1024) {
             if (i + 3 < nfl) {
-                *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(tile + i);
+                st4_stream(dst + i, *reinterpret_cast<const f32x4*>(tile + i), nt);
             } else {
                 for (int e = i; e < nfl; ++e) dst[e] = tile[e];
             }
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
                                                                   int B, int C, float inv_batch,
                                                                   float* __restrict__ dact, float* __restrict__ ll,
                                                                   double* __restrict__ partials, int nparts,
-                                                                  int tile_rows) {
+                                                                  int tile_rows, int nt) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ double red[4];
     __shared__ float sh_w;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
         const float* src = act + off;
         for (int i = tid * 4; i < nfl; i += 1024) {
             if (i + 3 < nfl) {
-                *reinterpret_cast<f32x4*>(tile + i) = *reinterpret_cast<const f32x4*>(src + i);
+                *reinterpret_cast<f32x4*>(tile + i) = ld4_stream(src + i, nt);
             } else {
                 for (int e = i; e < nfl; ++e) tile[e] = src[e];
             }
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
             float* dst = dact + off;
             for (int i = tid * 4; i < nfl; i += 1024) {
                 if (i + 3 < nfl) {
-                    *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(tile + i);
+                    st4_stream(dst + i, *reinterpret_cast<const f32x4*>(tile + i), nt);
                 } else {
                     for (int e = i; e < nfl; ++e) dst[e] = tile[e];
                 }
@@ -848,6 +849,7 @@ extern "C" int dun_ll_gauss(const float* act, const float* y, const float* log_s
     const bool vec = (B % 4 == 0) && aligned16(act) && aligned16(y) && (!dact || aligned16(dact)) &&
                      (!ll || aligned16(ll));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool nt = (size_t)D * B * 4 * (dact ? 2 : 1) >= NT_MIN_BYTES;
     if (vec && nparts >= 512) {
         // B >= 2^21: enough batch chunks to fill the chip without spreading single depths over workgroups, and act/dact
         // no longer fit the 256 MiB Infinity Cache: walk the depths inside the workgroup (measured: 4.9 -> 5.35 TB/s at
@@ -856,9 +858,16 @@ extern "C" int dun_ll_gauss(const float* act, const float* y, const float* log_s
         if (ny < ceil_div(D, GAUSS_DGROUP_MAX)) ny = ceil_div(D, GAUSS_DGROUP_MAX);
         if (ny > D) ny = D;
         const int dgroup = ceil_div(D, ny);
-        hipLaunchKernelGGL(ll_gauss_depths_kernel, dim3(nparts, ceil_div(D, dgroup)), dim3(256), 0, s, act, y, log_std, w,
-                           w_is_logits, D, B, inv_batch, dact, ll, partials, nparts, dgroup);
-    } else if (vec)
+        if (nt)
+            hipLaunchKernelGGL(ll_gauss_depths_kernel<true>, dim3(nparts, ceil_div(D, dgroup)), dim3(256), 0, s, act, y,
+                               log_std, w, w_is_logits, D, B, inv_batch, dact, ll, partials, nparts, dgroup);
+        else
+            hipLaunchKernelGGL(ll_gauss_depths_kernel<false>, dim3(nparts, ceil_div(D, dgroup)), dim3(256), 0, s, act, y,
+                               log_std, w, w_is_logits, D, B, inv_batch, dact, ll, partials, nparts, dgroup);
+    } else if (vec && nt)
+        hipLaunchKernelGGL((ll_gauss_kernel<true, true>), dim3(nparts, D), dim3(256), 0, s, act, y, log_std, w, w_is_logits,
+                           D, B, inv_batch, dact, ll, partials, nparts);
+    else if (vec)
         hipLaunchKernelGGL(ll_gauss_kernel<true>, dim3(nparts, D), dim3(256), 0, s, act, y, log_std, w, w_is_logits, D,
                            B, inv_batch, dact, ll, partials, nparts);
     else
@@ -883,17 +892,18 @@ extern "C" int dun_ll_softmax(const float* act, const int64_t* y, const float* w
     const int nparts = dun_ll_num_partials(B, C);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lds_ok = ((long long)B * C) % 4 == 0 && aligned16(act) && (!dact || aligned16(dact));
+    const int nt = (size_t)D * B * C * 4 * (dact ? 2 : 1) >= NT_MIN_BYTES ? 1 : 0;
     if (lds_ok && C <= 32) {
         const size_t lds = (size_t)ROWS_PER_BLOCK * C * sizeof(float);
         if (C <= 10)
             hipLaunchKernelGGL((ll_softmax_rowthread_kernel<10>), dim3(nparts, D), dim3(256), lds, s, act, y, w,
-                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts);
+                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts, nt);
         else if (C <= 16)
             hipLaunchKernelGGL((ll_softmax_rowthread_kernel<16>), dim3(nparts, D), dim3(256), lds, s, act, y, w,
-                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts);
+                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts, nt);
         else
             hipLaunchKernelGGL((ll_softmax_rowthread_kernel<32>), dim3(nparts, D), dim3(256), lds, s, act, y, w,
-                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts);
+                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts, nt);
     } else if (lds_ok) {
         // G lanes per row with at most 32 logits per lane; rows per pass: <= 32 KiB, a multiple of 4 (16-byte aligned
         // passes) and of the rows one sweep of the lane groups covers
@@ -907,7 +917,7 @@ extern "C" int dun_ll_softmax(const float* act, const int64_t* y, const float* w
         const size_t lds = (size_t)tile_rows * C * sizeof(float);
 #define DUN_RG(GG)                                                                                                  \
     hipLaunchKernelGGL((ll_softmax_rowgroup_kernel<GG, 32>), dim3(nparts, D), dim3(256), lds, s, act, y, w, w_is_logits, \
-                       D, B, C, inv_batch, dact, ll, partials, nparts, tile_rows)
+                       D, B, C, inv_batch, dact, ll, partials, nparts, tile_rows, nt)
         switch (g) {
             case 2: DUN_RG(2); break;
             case 4: DUN_RG(4); break;

@@ -14,7 +14,7 @@ namespace dun {
 constexpr int HSLAB_MAX = 1024;  // rows per dw partial (upper bound; small inputs take shorter slabs)
 constexpr int HCX = 64, HRY = 4;
 
-template <int OC, bool VEC>
+template <int OC, bool VEC, bool NT = false>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
                                                        const float* __restrict__ b, int rows, int K, int O,
                                                        float* __restrict__ act) {
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             for (int j = 0; j < OC; ++j) acc[j] = 0.f;
             if (VEC) {
                 for (int k = lane * 4; k < K; k += 256) {
-                    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + k);
+                    const f32x4 hv = ld4_stream<NT>(h + k);
 #pragma unroll
                     for (int j = 0; j < OC; ++j) {
                         if (o0 + j < O) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void head_fwd_rows_kernel(const float* __restr
 }
 
 // One workgroup: 64 column-chunks x 4 row lanes over a slab of slab_rows rows.  o0: first output of this launch.
-template <int OC, int VW>
+template <int OC, int VW, bool NT = false>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
                                                        const float* __restrict__ dact, int rows, int K, int O, int o0,
                                                        float* __restrict__ part_dw, float* __restrict__ part_db,
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         for (int r = slab * slab_rows + ty; r < r1; r += HRY) {
             float hv[VW];
             if (VW == 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(H + (size_t)r * K + c);
+                const f32x4 t = ld4_stream<NT>(H + (size_t)r * K + c);
                 hv[0] = t[0]; hv[1] = t[1]; hv[2] = t[2]; hv[3] = t[3];
             } else {
                 hv[0] = H[(size_t)r * K + c];
@@ -254,10 +254,12 @@ int head_forward(const float* H, const float* w, const float* b, int rows, int K
     }
     int grid = ceil_div(rows, 4);
     if (grid > 4096) grid = 4096;
+    const int nt = stream_nt((size_t)rows * K * 4) ? 1 : 0;  // H is read once: beyond the Infinity Cache, stream it
 #define HF(OC)                                                                                              \
     do {                                                                                                    \
-        if (vec) hipLaunchKernelGGL((head_fwd_kernel<OC, true>), dim3(grid), dim3(256), 0, s, H, w, b, rows, K, O, act); \
-        else hipLaunchKernelGGL((head_fwd_kernel<OC, false>), dim3(grid), dim3(256), 0, s, H, w, b, rows, K, O, act);    \
+        if (vec && nt) hipLaunchKernelGGL((head_fwd_kernel<OC, true, true>), dim3(grid), dim3(256), 0, s, H, w, b, rows, K, O, act); \
+        else if (vec) hipLaunchKernelGGL((head_fwd_kernel<OC, true>), dim3(grid), dim3(256), 0, s, H, w, b, rows, K, O, act); \
+        else hipLaunchKernelGGL((head_fwd_kernel<OC, false>), dim3(grid), dim3(256), 0, s, H, w, b, rows, K, O, act); \
     } while (0)
     switch (pick_oc(O)) {
         case 1: HF(1); break;
@@ -299,11 +301,15 @@ int head_backward(const float* H, const float* w, const float* dact, int rows, i
     float* part_db = ws + (size_t)nslab * O * K;
     const bool vec = K % 4 == 0 && aligned16(H) && aligned16(w) && (!dH || aligned16(dH));
     const int oc = pick_oc(O);
+    // H streamed once per launch; with several launches (O > 16) the default policy lets later ones hit the cache
+    const int nt = (stream_nt((size_t)rows * K * 4) && O <= oc) ? 1 : 0;
     for (int o0 = 0; o0 < O; o0 += oc) {
 #define HB(OC)                                                                                                   \
     do {                                                                                                         \
-        if (vec) hipLaunchKernelGGL((head_bwd_kernel<OC, 4>), dim3(ceil_div(K, HCX * 4), nslab), dim3(256), 0, s, H, w, \
-                                    dact, rows, K, O, o0, part_dw, part_db, dH, slab_rows);                      \
+        if (vec && nt) hipLaunchKernelGGL((head_bwd_kernel<OC, 4, true>), dim3(ceil_div(K, HCX * 4), nslab), dim3(256), 0, s, \
+                                          H, w, dact, rows, K, O, o0, part_dw, part_db, dH, slab_rows);          \
+        else if (vec) hipLaunchKernelGGL((head_bwd_kernel<OC, 4>), dim3(ceil_div(K, HCX * 4), nslab), dim3(256), 0, s, H, w, \
+                                         dact, rows, K, O, o0, part_dw, part_db, dH, slab_rows);                 \
         else hipLaunchKernelGGL((head_bwd_kernel<OC, 1>), dim3(ceil_div(K, HCX), nslab), dim3(256), 0, s, H, w, dact,   \
                                 rows, K, O, o0, part_dw, part_db, dH, slab_rows);                                \
     } while (0)

@@ -41,6 +41,8 @@ struct Vec<4> {
     typedef f32x4 T;
     static __device__ __forceinline__ T load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     static __device__ __forceinline__ void store(float* p, T v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ T load_nt(const float* p) { return ld4_stream<true>(p); }
+    static __device__ __forceinline__ void store_nt(float* p, T v) { st4_stream<true>(p, v); }
     static __device__ __forceinline__ float get(const T& v, int e) { return v[e]; }
     static __device__ __forceinline__ void set(T& v, int e, float x) { v[e] = x; }
 };
@@ -49,6 +51,8 @@ struct Vec<1> {
     typedef float T;
     static __device__ __forceinline__ T load(const float* p) { return *p; }
     static __device__ __forceinline__ void store(float* p, T v) { *p = v; }
+    static __device__ __forceinline__ T load_nt(const float* p) { return *p; }
+    static __device__ __forceinline__ void store_nt(float* p, T v) { *p = v; }
     static __device__ __forceinline__ float get(const T& v, int) { return v; }
     static __device__ __forceinline__ void set(T& v, int, float x) { v = x; }
 };
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* _
 }
 
 // h_out = [h_in +] gamma * (z - mean) * rstd + beta.  stat_is_var: `rstd` holds a variance (eval mode).
-template <int VW>
+template <int VW, bool NT = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ Z, const float* __restrict__ Hin,
                                                        float* __restrict__ Hout, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, int stat_is_var, float eps,
@@ -168,21 +172,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll 4
     for (int r = r0 + ty; r < r1; r += RY) {
         const size_t off = (size_t)r * W + c;
-        typename V::T z = V::load(Z + off), o;
+        typename V::T z = NT ? V::load_nt(Z + off) : V::load(Z + off), o;
         if (residual) {
-            typename V::T hi = V::load(Hin + off);
+            typename V::T hi = NT ? V::load_nt(Hin + off) : V::load(Hin + off);
 #pragma unroll
             for (int e = 0; e < VW; ++e) V::set(o, e, V::get(hi, e) + ((V::get(z, e) - mu[e]) * sc[e] + sh[e]));
         } else {
 #pragma unroll
             for (int e = 0; e < VW; ++e) V::set(o, e, (V::get(z, e) - mu[e]) * sc[e] + sh[e]);
         }
-        V::store(Hout + off, o);
+        if (NT) V::store_nt(Hout + off, o); else V::store(Hout + off, o);
     }
 }
 
 // per-slab column sums of g and g*xhat (xhat = (z-mean)*rstd): partials [2][P][W]
-template <int VW>
+template <int VW, bool NT = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ Z,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int B, int W, int P,
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll 4
         for (int r = slab * SLAB + ty; r < r1; r += RY) {
             const size_t off = (size_t)r * W + c;
-            const typename V::T g = V::load(G + off), z = V::load(Z + off);
+            const typename V::T g = NT ? V::load_nt(G + off) : V::load(G + off), z = NT ? V::load_nt(Z + off) : V::load(Z + off);
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
                 const float ge = V::get(g, e);
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // dU = (z > 0) * gamma * rstd * (g - sum_g/count - xhat * sum_gx/count); per-slab column sums of dU -> partials[P][W]
-template <int VW>
+template <int VW, bool NT = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ Z,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll 4
         for (int r = slab * SLAB + ty; r < r1; r += RY) {
             const size_t off = (size_t)r * W + c;
-            const typename V::T g = V::load(G + off), z = V::load(Z + off);
+            const typename V::T g = NT ? V::load_nt(G + off) : V::load(G + off), z = NT ? V::load_nt(Z + off) : V::load(Z + off);
             typename V::T o;
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 V::set(o, e, du);
                 acc[e] += du;
             }
-            V::store(dU + off, o);
+            if (NT) V::store_nt(dU + off, o); else V::store(dU + off, o);
         }
     }
 #pragma unroll
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // per-slab column sums of X [B,W] -> partials [P][W]
-template <int VW>
+template <int VW, bool NT = false>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int B, int W, int SLAB,
                                                      float* __restrict__ partials) {
     typedef Vec<VW> V;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
         const int r1 = min(B, (slab + 1) * SLAB);
 #pragma unroll 4
         for (int r = slab * SLAB + ty; r < r1; r += RY) {
-            const typename V::T x = V::load(X + (size_t)r * W + c);
+            const typename V::T x = NT ? V::load_nt(X + (size_t)r * W + c) : V::load(X + (size_t)r * W + c);
 #pragma unroll
             for (int e = 0; e < VW; ++e) acc[e] += V::get(x, e);
         }
@@ -468,9 +472,14 @@ static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream
     const float* gamma = c->p.gamma + (size_t)i * W;
     const float* beta = c->p.beta + (size_t)i * W;
     const int rpb = 32;
+    const int nt = stream_nt((size_t)B * W * 4) ? 1 : 0;  // [B,W] planes beyond the Infinity Cache are streamed
     if (vec4_ok(W, Z, hin, hout)) {
-        hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ceil_div(W, CX * 4), ceil_div(B, rpb)), dim3(256), 0, s, Z, hin, hout,
-                           mean, stat, is_var, c->bn_eps, gamma, beta, B, W, c->residual, rpb);
+        if (nt)
+            hipLaunchKernelGGL((bn_apply_kernel<4, true>), dim3(ceil_div(W, CX * 4), ceil_div(B, rpb)), dim3(256), 0, s, Z,
+                               hin, hout, mean, stat, is_var, c->bn_eps, gamma, beta, B, W, c->residual, rpb);
+        else
+            hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ceil_div(W, CX * 4), ceil_div(B, rpb)), dim3(256), 0, s, Z, hin,
+                               hout, mean, stat, is_var, c->bn_eps, gamma, beta, B, W, c->residual, rpb);
     } else {
         hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ceil_div(W, CX), ceil_div(B, rpb)), dim3(256), 0, s, Z, hin, hout,
                            mean, stat, is_var, c->bn_eps, gamma, beta, B, W, c->residual, rpb);
@@ -511,13 +520,18 @@ static int bwd_begin(const dun_fc_ctx* c, hipStream_t s) {
 
 static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
     const int W = c->W, B = c->B, P = num_slabs(B);
+    const int nt = stream_nt((size_t)B * W * 4) ? 1 : 0;
     const float* Z = Zd(c, i);
     const float* mean = c->bn_mean + (size_t)i * W;
     const float* rstd = c->bn_rstd + (size_t)i * W;
-    if (vec4_ok(W, c->G, Z))
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean, rstd, B,
-                           W, P, slab_rows_for(B), c->ws);
-    else
+    if (vec4_ok(W, c->G, Z)) {
+        if (nt)
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean,
+                               rstd, B, W, P, slab_rows_for(B), c->ws);
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean, rstd,
+                               B, W, P, slab_rows_for(B), c->ws);
+    } else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, Z, mean, rstd, B, W,
                            P, slab_rows_for(B), c->ws);
     DUN_LAUNCH_CHECK();
@@ -530,14 +544,19 @@ static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
 
 static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s) {
     const int W = c->W, B = c->B, P = num_slabs(B);
+    const int nt = stream_nt((size_t)B * W * 4) ? 1 : 0;
     const float* Z = Zd(c, i);
     const float* mean = c->bn_mean + (size_t)i * W;
     const float* rstd = c->bn_rstd + (size_t)i * W;
     const float* gamma = c->p.gamma + (size_t)i * W;
-    if (vec4_ok(W, c->G, Z, c->dU))
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean, rstd,
-                           gamma, c->bn_sums, global_batch, B, W, slab_rows_for(B), c->dU, c->ws);
-    else
+    if (vec4_ok(W, c->G, Z, c->dU)) {
+        if (nt)
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean,
+                               rstd, gamma, c->bn_sums, global_batch, B, W, slab_rows_for(B), c->dU, c->ws);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean, rstd,
+                               gamma, c->bn_sums, global_batch, B, W, slab_rows_for(B), c->dU, c->ws);
+    } else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, Z, mean, rstd, gamma,
                            c->bn_sums, global_batch, B, W, slab_rows_for(B), c->dU, c->ws);
     DUN_LAUNCH_CHECK();
@@ -567,6 +586,7 @@ static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipS
 
 static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
     const int W = c->W, B = c->B, P = num_slabs(B);
+    const int nt = stream_nt((size_t)B * W * 4) ? 1 : 0;
     // dW_in[n_out, k] = sum_b G[b, n_out] * x[b, k]
     dun_gemm_desc g;
     memset(&g, 0, sizeof(g));
@@ -577,9 +597,14 @@ static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
     g.splitk_ws = c->ws; g.splitk_ws_floats = c->ws_floats;  // ws is free here; colsum below reuses it afterwards
     int rc = gemm_f32(&g, s);
     if (rc) return rc;
-    if (vec4_ok(W, c->G))
-        hipLaunchKernelGGL(colsum_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, B, W, slab_rows_for(B), c->ws);
-    else
+    if (vec4_ok(W, c->G)) {
+        if (nt)
+            hipLaunchKernelGGL((colsum_kernel<4, true>), dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, B, W,
+                               slab_rows_for(B), c->ws);
+        else
+            hipLaunchKernelGGL(colsum_kernel<4>, dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, B, W, slab_rows_for(B),
+                               c->ws);
+    } else
         hipLaunchKernelGGL(colsum_kernel<1>, dim3(ceil_div(W, CX), P), dim3(256), 0, s, c->G, B, W, slab_rows_for(B), c->ws);
     DUN_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, RCX), 1), dim3(256), 0, s, c->ws, P, W,
