@@ -199,20 +199,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
 }
 
-// out[c] = sum_p partials[p][c] in fp64, fixed order (64 columns x 4 partial lanes per workgroup)
-__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ partials, int P, size_t n,
-                                                          float* __restrict__ out) {
-    __shared__ double red[HRY][HCX];
-    const int tx = threadIdx.x & (HCX - 1), ty = threadIdx.x >> 6;
-    const size_t c = (size_t)blockIdx.x * HCX + tx;
-    double s = 0.0;
-    if (c < n)
-        for (int p = ty; p < P; p += HRY) s += (double)partials[(size_t)p * n + c];
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && c < n) out[c] = (float)((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
-}
-
+// out[c] = sum_p partials[p][c] in fp64, fixed order (64 columns x 4 partial lanes per workgroup);
 // the weight- and bias-gradient partials in ONE launch: workgroups [0, nb_w) reduce dw, the rest db (same arithmetic)
 __global__ __launch_bounds__(256) void head_reduce2_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b,
                                                            int P, size_t n_w, size_t n_b, int nb_w,
