@@ -520,7 +520,7 @@ __device__ __forceinline__ float rounded(float x) {
     return x;
 }
 
-template <bool VEC>
+template <bool VEC, bool NT = false>
 __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restrict__ act, const float* __restrict__ q,
                                                             int D, int n, float* __restrict__ mean,
                                                             float* __restrict__ std, const float* __restrict__ y,
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
             const float* a = act + (size_t)d * n + idx;
             float v[4];
             if (VEC) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(a);
+                const f32x4 t = ld4_stream<NT>(a);
                 v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
             } else {
 #pragma unroll
@@ -968,7 +968,10 @@ extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n,
     // one workgroup: its [2][1] partials ARE the metric sums, no reduction launch
     double* part = metrics ? (nparts == 1 ? metrics : partials) : nullptr;
     const bool vec = (n % 4 == 0) && aligned16(act);
-    if (vec)
+    if (vec && stream_nt((size_t)D * n * 4))
+        hipLaunchKernelGGL((predict_gauss_kernel<true, true>), dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
+                           log_std, part, nparts);
+    else if (vec)
         hipLaunchKernelGGL(predict_gauss_kernel<true>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
                            log_std, part, nparts);
     else
