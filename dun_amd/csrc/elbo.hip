@@ -275,11 +275,11 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
             v[k] = k < C ? a[k] : -INFINITY;
             mx = fmaxf(mx, v[k]);
         }
-        const int yb = (int)y[r0 + tid];
-        float s = 0.f, ay = 0.f;
+        const int yb = min(max((int)y[r0 + tid], 0), C - 1);  // (a label outside [0,C) is clamped, not chased out of the tile)
+        const float ay = a[yb];  // the target's logit straight from the staged row (no select per class)
+        float s = 0.f;
 #pragma unroll
         for (int k = 0; k < CMAX; ++k) {
-            ay = k == yb ? v[k] : ay;
             v[k] = expf(v[k] - mx);  // exp(-inf) = 0 for the padding
             s += v[k];
         }
@@ -288,10 +288,13 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
         acc = row_ll;
         if (ll) ll[(size_t)d * B + r0 + tid] = row_ll;
         if (dact) {
-            const float inv_s = 1.f / s;
+            // -coef (onehot - softmax) = (coef / s) exp(.) everywhere, minus coef at the target class
+            const float sc = coef / s;
+            const float gy = sc * expf(ay - mx) - coef;
 #pragma unroll
             for (int k = 0; k < CMAX; ++k)
-                if (k < C) a[k] = -coef * ((k == yb ? 1.f : 0.f) - v[k] * inv_s);
+                if (k < C) a[k] = sc * v[k];
+            a[yb] = gy;
         }
     }
     if (dact) {
