@@ -239,30 +239,36 @@ __global__ __launch_bounds__(256) void ll_softmax_kernel(const float* __restrict
 // instead: C LDS reads, max / exp / sum / log in registers, C LDS writes, no shuffle, all 64 lanes busy.
 // One pass: the workgroup's 256 rows (<= 32 KiB) in, gradient out, both with 16-byte lane accesses (4.5 TB/s at C = 10).
 // Needs B*C % 4 == 0 and 16-byte aligned act/dact; anything else, and C > 32, takes the lane-group kernel.
-template <int CMAX>
+template <int CMAX, bool NT>
 __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* __restrict__ act,
                                                                    const int64_t* __restrict__ y,
                                                                    const float* __restrict__ w, int w_is_logits, int D,
                                                                    int B, int C, float inv_batch,
                                                                    float* __restrict__ dact, float* __restrict__ ll,
-                                                                   double* __restrict__ partials, int nparts, int nt) {
+                                                                   double* __restrict__ partials, int nparts) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ double red[4];
     __shared__ float sh_w;
     const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
-    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
-    const float coef = wd * inv_batch;
     const int r0 = part * ROWS_PER_BLOCK;
     const int nrows = min(ROWS_PER_BLOCK, B - r0);
-    const int nfl = nrows * C;
-    const size_t off = ((size_t)d * B + r0) * C;  // multiple of 4 floats: r0 % 4 == 0 and B*C % 4 == 0
+    const int nfl = nrows * C;  // a multiple of 4: r0 % 4 == 0 and B*C % 4 == 0
+    const size_t off = ((size_t)d * B + r0) * C;
     const float* src = act + off;
-    for (int i = tid * 4; i < nfl; i += 1024) {
-        if (i + 3 < nfl) {
-            *reinterpret_cast<f32x4*>(tile + i) = ld4_stream(src + i, nt);
-        } else {
-            for (int e = i; e < nfl; ++e) tile[e] = src[e];
-        }
+    // every global load of the workgroup is issued before anything waits: the label, then the thread's share of the
+    // tile into registers (a run-time trip count made this a load / wait / LDS-store round trip per 4 KiB; branch-free,
+    // clamped addresses), and the depth weight (scalar loads, a wave reduction and a barrier) is worked out underneath
+    const int64_t yv = y[r0 + min(tid, nrows - 1)];
+    constexpr int NV = (ROWS_PER_BLOCK * CMAX / 4 + 255) / 256;
+    f32x4 stage[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) stage[j] = ld4_stream<NT>(src + min((j * 256 + tid) * 4, nfl - 4));
+    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
+    const float coef = wd * inv_batch;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (j * 256 + tid) * 4;
+        if (i < nfl) *reinterpret_cast<f32x4*>(tile + i) = stage[j];
     }
     __syncthreads();
     float acc = 0.f;
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
             v[k] = k < C ? a[k] : -INFINITY;
             mx = fmaxf(mx, v[k]);
         }
-        const int yb = min(max((int)y[r0 + tid], 0), C - 1);  // (a label outside [0,C) is clamped, not chased out of the tile)
+        const int yb = min(max((int)yv, 0), C - 1);  // (a label outside [0,C) is clamped, not chased out of the tile)
         const float ay = a[yb];  // the target's logit straight from the staged row (no select per class)
         float s = 0.f;
 #pragma unroll
@@ -300,12 +306,10 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
     if (dact) {
         __syncthreads();
         float* dst = dact + off;
-        for (int i = tid * 4; i < nfl; i += 1024) {
-            if (i + 3 < nfl) {
-                st4_stream(dst + i, *reinterpret_cast<const f32x4*>(tile + i), nt);
-            } else {
-                for (int e = i; e < nfl; ++e) dst[e] = tile[e];
-            }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = (j * 256 + tid) * 4;
+            if (i < nfl) st4_stream<NT>(dst + i, *reinterpret_cast<const f32x4*>(tile + i));
         }
     }
     const double tot = block_sum<256, double>((double)acc, red);
@@ -314,37 +318,57 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
 
 // 32 < C <= 1024 (CIFAR-100 / ImageNet-sized heads): the same LDS staging with G lanes per row (C/G <= 32 logits per
 // lane in registers, log2 G shuffle levels per reduction instead of six), `tile_rows` rows per pass (<= 32 KiB).
-template <int G, int KMAX>
+template <int G, int KMAX, bool NT>
 __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* __restrict__ act,
                                                                   const int64_t* __restrict__ y,
                                                                   const float* __restrict__ w, int w_is_logits, int D,
                                                                   int B, int C, float inv_batch,
                                                                   float* __restrict__ dact, float* __restrict__ ll,
                                                                   double* __restrict__ partials, int nparts,
-                                                                  int tile_rows, int nt) {
+                                                                  int tile_rows) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ double red[4];
     __shared__ float sh_w;
+    __shared__ int ytile[ROWS_PER_BLOCK];
     const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     const int gl = tid % G, grp = tid / G;
     constexpr int NGROUPS = 256 / G;
+    constexpr int NV = 8;  // float4 per thread and pass: a pass is at most 32 KiB
+    const int row_begin = part * ROWS_PER_BLOCK;
+    const int row_end = min(B, row_begin + ROWS_PER_BLOCK);
+    // Loads first, waits later: the labels of all rows of the workgroup (one per thread, kept in LDS: a load per row
+    // inside the row loop was a dependent global round trip per row) and the first pass of logits into registers
+    // (branch-free, clamped addresses; pass sizes are multiples of 4 floats: r0 % 4 == 0 and B*C % 4 == 0); the depth
+    // weight is worked out underneath them.  The logits of pass p+1 are fetched into the same registers while pass p
+    // is reduced out of LDS.
+    const int yv = (int)y[row_begin + min(tid, row_end - row_begin - 1)];
+    f32x4 stage[NV];
+    {
+        const int nfl0 = min(tile_rows, row_end - row_begin) * C;
+        const float* src0 = act + ((size_t)d * B + row_begin) * C;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) stage[j] = ld4_stream<NT>(src0 + min((j * 256 + tid) * 4, nfl0 - 4));
+    }
+    ytile[tid] = yv;
     const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
     const float coef = wd * inv_batch;
-    const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
     float acc = 0.f;
-    for (int r0 = part * ROWS_PER_BLOCK; r0 < row_end; r0 += tile_rows) {
+    for (int r0 = row_begin; r0 < row_end; r0 += tile_rows) {
         const int nrows = min(tile_rows, row_end - r0);
         const int nfl = nrows * C;
-        const size_t off = ((size_t)d * B + r0) * C;  // multiple of 4 floats: r0 % 4 == 0 and B*C % 4 == 0
-        const float* src = act + off;
-        for (int i = tid * 4; i < nfl; i += 1024) {
-            if (i + 3 < nfl) {
-                *reinterpret_cast<f32x4*>(tile + i) = ld4_stream(src + i, nt);
-            } else {
-                for (int e = i; e < nfl; ++e) tile[e] = src[e];
-            }
+        const size_t off = ((size_t)d * B + r0) * C;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = (j * 256 + tid) * 4;
+            if (i < nfl) *reinterpret_cast<f32x4*>(tile + i) = stage[j];
         }
         __syncthreads();
+        if (r0 + tile_rows < row_end) {  // (uniform) next pass on its way while this one is reduced
+            const int nfl1 = min(tile_rows, row_end - r0 - tile_rows) * C;
+            const float* src1 = act + off + (size_t)tile_rows * C;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) stage[j] = ld4_stream<NT>(src1 + min((j * 256 + tid) * 4, nfl1 - 4));
+        }
         for (int row = grp; row < nrows; row += NGROUPS) {  // (uniform per group: the shuffles below stay converged)
             float* a = tile + row * C;
             float v[KMAX];
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
                 mx = fmaxf(mx, v[k]);
             }
             mx = group_max<G>(mx);
-            const int yb = (int)y[r0 + row];
+            const int yb = ytile[r0 - row_begin + row];
             float s = 0.f, ay = 0.f;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
@@ -383,12 +407,10 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
         __syncthreads();
         if (dact) {
             float* dst = dact + off;
-            for (int i = tid * 4; i < nfl; i += 1024) {
-                if (i + 3 < nfl) {
-                    st4_stream(dst + i, *reinterpret_cast<const f32x4*>(tile + i), nt);
-                } else {
-                    for (int e = i; e < nfl; ++e) dst[e] = tile[e];
-                }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = (j * 256 + tid) * 4;
+                if (i < nfl) st4_stream<NT>(dst + i, *reinterpret_cast<const f32x4*>(tile + i));
             }
             __syncthreads();  // the next pass overwrites the tile
         }
@@ -898,15 +920,22 @@ extern "C" int dun_ll_softmax(const float* act, const int64_t* y, const float* w
     const int nt = (size_t)D * B * C * 4 * (dact ? 2 : 1) >= NT_MIN_BYTES ? 1 : 0;
     if (lds_ok && C <= 32) {
         const size_t lds = (size_t)ROWS_PER_BLOCK * C * sizeof(float);
+#define DUN_RT(CM)                                                                                                   \
+    do {                                                                                                             \
+        if (nt)                                                                                                      \
+            hipLaunchKernelGGL((ll_softmax_rowthread_kernel<CM, true>), dim3(nparts, D), dim3(256), lds, s, act, y, w, \
+                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts);                         \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ll_softmax_rowthread_kernel<CM, false>), dim3(nparts, D), dim3(256), lds, s, act, y, \
+                               w, w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts);                      \
+    } while (0)
         if (C <= 10)
-            hipLaunchKernelGGL((ll_softmax_rowthread_kernel<10>), dim3(nparts, D), dim3(256), lds, s, act, y, w,
-                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts, nt);
+            DUN_RT(10);
         else if (C <= 16)
-            hipLaunchKernelGGL((ll_softmax_rowthread_kernel<16>), dim3(nparts, D), dim3(256), lds, s, act, y, w,
-                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts, nt);
+            DUN_RT(16);
         else
-            hipLaunchKernelGGL((ll_softmax_rowthread_kernel<32>), dim3(nparts, D), dim3(256), lds, s, act, y, w,
-                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts, nt);
+            DUN_RT(32);
+#undef DUN_RT
     } else if (lds_ok) {
         // G lanes per row with at most 32 logits per lane; rows per pass: <= 32 KiB, a multiple of 4 (16-byte aligned
         // passes) and of the rows one sweep of the lane groups covers
@@ -919,8 +948,14 @@ extern "C" int dun_ll_softmax(const float* act, const int64_t* y, const float* w
         if (tile_rows > ROWS_PER_BLOCK) tile_rows = ROWS_PER_BLOCK;
         const size_t lds = (size_t)tile_rows * C * sizeof(float);
 #define DUN_RG(GG)                                                                                                  \
-    hipLaunchKernelGGL((ll_softmax_rowgroup_kernel<GG, 32>), dim3(nparts, D), dim3(256), lds, s, act, y, w, w_is_logits, \
-                       D, B, C, inv_batch, dact, ll, partials, nparts, tile_rows, nt)
+    do {                                                                                                            \
+        if (nt)                                                                                                     \
+            hipLaunchKernelGGL((ll_softmax_rowgroup_kernel<GG, 32, true>), dim3(nparts, D), dim3(256), lds, s, act, y, w, \
+                               w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts, tile_rows);             \
+        else                                                                                                        \
+            hipLaunchKernelGGL((ll_softmax_rowgroup_kernel<GG, 32, false>), dim3(nparts, D), dim3(256), lds, s, act, y, \
+                               w, w_is_logits, D, B, C, inv_batch, dact, ll, partials, nparts, tile_rows);          \
+    } while (0)
         switch (g) {
             case 2: DUN_RG(2); break;
             case 4: DUN_RG(4); break;
