@@ -696,21 +696,22 @@ __global__ __launch_bounds__(256) void predict_softmax_kernel(const float* __res
 // Here the rows of one depth are one contiguous run: it is prefetched into registers with 16-byte lane accesses while
 // the previous depth is reduced out of LDS, G lanes own a row (G = 1 for C <= 32: a thread per row, no shuffles) and
 // keep its running sum_d q_d softmax(a_d) in registers; probabilities leave through the same LDS tile.
-template <int G, int KMAX>
+template <int G, int KMAX, bool NT>
 __global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* __restrict__ act,
                                                                   const float* __restrict__ q, int D, int B, int C,
                                                                   float* __restrict__ probs,
                                                                   const int64_t* __restrict__ y,
-                                                                  double* __restrict__ partials, int nparts) {
+                                                                  double* __restrict__ partials, int nparts,
+                                                                  int rows_wg) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ double red[4];
     constexpr int RPP = 256 / G;  // rows per pass
-    constexpr int NF = 8;         // float4 per thread and tile: RPP * C <= 8192 floats
+    constexpr int NF = (KMAX + 3) / 4;  // float4 per thread and tile: RPP * C <= 256 * KMAX floats
     const int part = blockIdx.x, tid = threadIdx.x;
     const int gl = tid % G, grp = tid / G;
-    const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
+    const int row_end = min(B, (part + 1) * rows_wg);  // rows_wg: a multiple of RPP
     double nll = 0.0, nerr = 0.0;
-    for (int r0 = part * ROWS_PER_BLOCK; r0 < row_end; r0 += RPP) {
+    for (int r0 = part * rows_wg; r0 < row_end; r0 += RPP) {
         const int nrows = min(RPP, row_end - r0);
         const int nfl = nrows * C;
         const bool mine = grp < nrows;
@@ -718,20 +719,13 @@ __global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* _
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) pr[k] = 0.f;
         f32x4 pre[NF];
+        // branch-free, clamped addresses (tile sizes are multiples of 4 floats): a branch per load serialises them
         auto fetch = [&](int d) {
             const float* src = act + ((size_t)d * B + r0) * C;  // multiple of 4 floats (r0 % 4 == 0, B*C % 4 == 0)
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const int i = (f * 256 + tid) * 4;
-                pre[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i + 3 < nfl) {
-                    pre[f] = *reinterpret_cast<const f32x4*>(src + i);
-                } else if (i < nfl) {
-                    for (int e = 0; e < 4; ++e)
-                        if (i + e < nfl) pre[f][e] = src[i + e];
-                }
-            }
+            for (int f = 0; f < NF; ++f) pre[f] = ld4_stream<NT>(src + min((f * 256 + tid) * 4, nfl - 4));
         };
+        const int yb = partials ? (int)y[r0 + min(grp, nrows - 1)] : 0;  // on its way under the whole depth loop
         fetch(0);
         for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -771,7 +765,6 @@ __global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* _
             for (int k = 0; k < KMAX; ++k)
                 if (gl + k * G < C) o[gl + k * G] = pr[k];
             if (partials) {
-                const int yb = (int)y[r0 + grp];
                 float py = 0.f, best = -INFINITY;
                 int bi = 0x7fffffff;
 #pragma unroll
@@ -797,12 +790,10 @@ __global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* _
         }
         __syncthreads();
         float* dst = probs + (size_t)r0 * C;  // r0 * C % 4 == 0
-        for (int i = tid * 4; i < nfl; i += 1024) {
-            if (i + 3 < nfl) {
-                *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(tile + i);
-            } else {
-                for (int e = i; e < nfl; ++e) dst[e] = tile[e];
-            }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int i = (f * 256 + tid) * 4;
+            if (i < nfl) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(tile + i);
         }
         __syncthreads();  // the next pass overwrites the tile
     }
@@ -824,6 +815,18 @@ static int softmax_group(int C, int* kmax) {
     while (G * k < C) k <<= 1;
     *kmax = k;
     return G;
+}
+
+// Rows of the depth-marginal softmax predictor per workgroup.  The LDS kernel reduces 256/g rows per pass (g lanes per
+// row); 256 rows per workgroup keep the partial count small on large batches, but a small batch of wide rows
+// (4096 x 100 classes: 16 workgroups walking 4 passes x D depths each) leaves the chip empty: one pass per workgroup
+// until there are at least four workgroups per CU.
+static int predict_rows_per_wg(int B, int C, bool lds_path) {
+    if (!lds_path) return ROWS_PER_BLOCK;
+    int g = 1;
+    while (g * 32 < C) g <<= 1;
+    const int rpp = 256 / g;
+    return ceil_div(B, ROWS_PER_BLOCK) >= 1024 ? ROWS_PER_BLOCK : rpp;
 }
 
 #define DUN_SOFTMAX_DISPATCH(KERNEL, G, KM, grid, s, ...) DUN_SOFTMAX_DISPATCH_LDS(KERNEL, G, KM, grid, 0, s, __VA_ARGS__)
@@ -860,7 +863,8 @@ extern "C" int dun_ll_num_partials(int B, int C) {
 
 extern "C" int dun_predict_num_partials(int n, int C) {
     if (n <= 0) return 0;
-    return C <= 1 ? ceil_div(n, 1024) : ceil_div(n, ROWS_PER_BLOCK);
+    if (C <= 1) return ceil_div(n, 1024);
+    return ceil_div(n, predict_rows_per_wg(n, C, true));  // an upper bound of what dun_predict_softmax launches
 }
 
 extern "C" int dun_ll_gauss(const float* act, const float* y, const float* log_std, const float* w, int w_is_logits,
@@ -1034,17 +1038,25 @@ extern "C" int dun_predict_softmax(const float* act, const float* q, int D, int 
     }
     int km;
     const int G = softmax_group(C, &km);
-    const int nparts = dun_predict_num_partials(B, C > 1 ? C : 2);
+    const bool lds_ok = ((long long)B * C) % 4 == 0 && aligned16(act) && aligned16(probs);
+    const int rows_wg = predict_rows_per_wg(B, C, lds_ok);
+    const int nparts = ceil_div(B, rows_wg);  // <= dun_predict_num_partials(B, C), which sizes the caller's buffer
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* part = metrics ? (nparts == 1 ? metrics : partials) : nullptr;
-    const bool lds_ok = ((long long)B * C) % 4 == 0 && aligned16(act) && aligned16(probs);
     if (lds_ok) {
         int g = 1;
         while (g * 32 < C) g <<= 1;
         const size_t lds = ((size_t)(256 / g) * C + 4) * sizeof(float);
+        const bool nt = stream_nt((size_t)D * B * C * 4);
 #define DUN_PS(GG, KK)                                                                                            \
-    hipLaunchKernelGGL((predict_softmax_lds_kernel<GG, KK>), dim3(nparts), dim3(256), lds, s, act, q, D, B, C, probs, y, \
-                       part, nparts)
+    do {                                                                                                          \
+        if (nt)                                                                                                   \
+            hipLaunchKernelGGL((predict_softmax_lds_kernel<GG, KK, true>), dim3(nparts), dim3(256), lds, s, act, q, D, B, \
+                               C, probs, y, part, nparts, rows_wg);                                               \
+        else                                                                                                      \
+            hipLaunchKernelGGL((predict_softmax_lds_kernel<GG, KK, false>), dim3(nparts), dim3(256), lds, s, act, q, D, \
+                               B, C, probs, y, part, nparts, rows_wg);                                            \
+    } while (0)
         if (C <= 10) DUN_PS(1, 10);
         else if (C <= 16) DUN_PS(1, 16);
         else if (g == 1) DUN_PS(1, 32);

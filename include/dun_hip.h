@@ -96,6 +96,8 @@ int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mea
  *   metrics (nullable, double [2]; needs y int64 [B]): sum_b -log probs[b,y_b], count(argmax != y). */
 int dun_predict_softmax(const float* act, const float* q, int D, int B, int C, float* probs, const int64_t* y,
                         double* partials, double* metrics, dun_stream_t stream);
+/* Size of `partials` for the two predictors: double [2][dun_predict_num_partials(n, C)] (an upper bound of the
+ * workgroups a call launches; C = 1 for the Gaussian predictor). */
 int dun_predict_num_partials(int n, int C);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -180,7 +180,9 @@ def test_elbo_softmax_edges(be, C):
                                     # 32 < C <= 1024: G lanes per row out of LDS (2, 4, 8, 16, 32), several passes per
                                     # workgroup, ragged last pass; and the unaligned fallback
                                     (3, 1000, 64), (3, 516, 100), (2, 300, 200), (2, 260, 500), (2, 70, 1000),
-                                    (2, 51, 101)])
+                                    (2, 51, 101),
+                                    # >= 1024 workgroups of 256 rows: the predictor walks several passes per workgroup
+                                    (2, 262148, 64)])
 def test_elbo_softmax_sizes(be, D, B, C):
     g = torch.Generator().manual_seed(D * 100003 + B * 7 + C)
     act = 3.0 * torch.randn(D, B, C, generator=g)
