@@ -31,18 +31,21 @@ class Shard(object):
         self.overlap = overlap
         self._pending = []
         self.grad_group = group
+        # rehearsal switch (scripts/shard_rehearsal.py): issue every collective even in a one-rank group, so the
+        # stream hand-offs, async handles and message order of the N-GPU step run on a one-GPU box
+        self.force_collectives = False
 
     def global_batch(self, local_batch):
         return local_batch * self.world
 
     def all_reduce(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def reduce_gradient_async(self, t, exclude=None):
         """SUM all-reduce of a gradient slice; `exclude` is a sub-range of `t`'s storage that was already sent."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         pieces = [t]
         if exclude is not None:

@@ -1,6 +1,8 @@
 """Per-rank cost of the N-GPU sharded step, rehearsed on one GPU: the staged (BN-exchange) path at the local batch
-B/N of the c3_wide workload with a world-size-1 RCCL group (collectives are no-ops; kernels + host staging are real)."""
-import os, sys, time
+B/N of the c3_wide workload with a world-size-1 RCCL group (kernels + host staging are real; the "staged+coll" rows
+also ISSUE every collective of the N-GPU step -- BatchNorm exchanges, per-block async gradient messages, likelihood
+sums -- on the one-rank communicator: stream hand-offs, async handles and message order run, the wire does not)."""
+import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
@@ -12,10 +14,11 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 din, W, L, B, N_train, lr, mom, wd = bench.WORKLOADS["c3_wide"]
 for N in (8, 4, 2, 1):
     Bl = B // N
-    for sharded in (False, True):
+    for sharded in (False, True, "coll"):
         net = bench.build_net(din, W, L, N_train, lr, mom, wd)
         if sharded:
-            shard(net, sync_bn=True)
+            spec = shard(net, sync_bn=True)
+            spec.force_collectives = sharded == "coll"
         x, y = bench.shard_data(Bl, din, 0, torch.device("cuda"))
         for _ in range(2):
             net.fit(x, y)
@@ -26,8 +29,9 @@ for N in (8, 4, 2, 1):
         t0 = time.perf_counter()
         net.fit(x, y)
         host = time.perf_counter() - t0   # time until fit returns (includes the metrics D2H sync)
-        print("N=%d local batch %6d %-9s %.2f ms/step  (ideal-scaling throughput %.0f samples/s)" %
-              (N, Bl, "staged" if sharded else "fused", dt * 1e3, B / dt), flush=True)
+        print("N=%d local batch %6d %-11s %.2f ms/step  (ideal-scaling throughput %.0f samples/s)" %
+              (N, Bl, "staged+coll" if sharded == "coll" else "staged" if sharded else "fused", dt * 1e3, B / dt), flush=True)
         del net
+        gc.collect()  # (module <-> buffer cycles: without it the 55 GB of the previous variant stay allocated)
         torch.cuda.empty_cache()
 dist.destroy_process_group()
