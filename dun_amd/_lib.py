@@ -19,7 +19,7 @@ EXPORTS = [
     "dun_abi_version", "dun_last_error", "dun_ll_num_partials", "dun_ll_gauss", "dun_ll_softmax", "dun_ll_reduce",
     "dun_depth_finalize", "dun_predict_gauss", "dun_predict_softmax", "dun_predict_num_partials", "dun_gemm_f32", "dun_gemm_colstat_tiles",
     "dun_fc_workspace_floats", "dun_fc_forward", "dun_fc_backward", "dun_fc_input_layer", "dun_fc_block_linear",
-    "dun_fc_block_norm", "dun_fc_head", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply",
+    "dun_fc_block_norm", "dun_fc_head", "dun_fc_head_depth", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply", "dun_fc_bwd_block_dx", "dun_fc_bwd_block_dw",
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
 ]
 
@@ -80,9 +80,12 @@ def _declare(lib):
         "dun_fc_block_linear": (i, [C.POINTER(FcCtx), i, vp]),
         "dun_fc_block_norm": (i, [C.POINTER(FcCtx), i, d, vp]),
         "dun_fc_head": (i, [C.POINTER(FcCtx), vp]),
+        "dun_fc_head_depth": (i, [C.POINTER(FcCtx), i, vp]),
         "dun_fc_bwd_begin": (i, [C.POINTER(FcCtx), vp]),
         "dun_fc_bwd_block_reduce": (i, [C.POINTER(FcCtx), i, vp]),
         "dun_fc_bwd_block_apply": (i, [C.POINTER(FcCtx), i, d, vp]),
+        "dun_fc_bwd_block_dx": (i, [C.POINTER(FcCtx), i, d, vp]),
+        "dun_fc_bwd_block_dw": (i, [C.POINTER(FcCtx), i, vp]),
         "dun_fc_bwd_end": (i, [C.POINTER(FcCtx), vp]),
         "dun_head_forward": (i, [vp, vp, vp, i, i, i, vp, vp]),
         "dun_head_backward_workspace_floats": (sz, [i, i, i]),

@@ -542,7 +542,8 @@ static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
     return DUN_OK;
 }
 
-static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s) {
+// BatchNorm + ReLU backward of block i: dU, db_i (the exchanged column sums are in bn_sums)
+static int bwd_block_du(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s) {
     const int W = c->W, B = c->B, P = num_slabs(B);
     const int nt = stream_nt((size_t)B * W * 4) ? 1 : 0;
     const float* Z = Zd(c, i);
@@ -563,25 +564,41 @@ static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipS
     hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, RCX), 1), dim3(256), 0, s, c->ws, P, W,
                        (double*)nullptr, c->g.b + (size_t)i * W, (float*)nullptr);
     DUN_LAUNCH_CHECK();
-    // dW_i[n_out, k_in] = sum_b dU[b, n_out] * H_i[b, k_in]
+    return DUN_OK;
+}
+
+// dW_i[n_out, k_in] = sum_b dU[b, n_out] * H_i[b, k_in]   (dU of block i must still be in place)
+static int bwd_block_dw(const dun_fc_ctx* c, int i, hipStream_t s) {
+    const int W = c->W;
     dun_gemm_desc g;
     memset(&g, 0, sizeof(g));
     g.A = c->dU; g.lda = W; g.a_kcontig = 0;
     g.B = Hd(c, i); g.ldb = W; g.b_kcontig = 0;
     g.C = c->g.w + (size_t)i * W * W; g.ldc = W;
-    g.M = W; g.N = W; g.K = B;
-    g.splitk_ws = c->ws; g.splitk_ws_floats = c->ws_floats;  // the bias partials in ws were consumed just above
-    int rc = gemm_f32(&g, s);
-    if (rc) return rc;
-    // g <- [g +] dU W_i + dact_i w_out   (in place: every element is read and written by its own thread)
+    g.M = W; g.N = W; g.K = c->B;
+    g.splitk_ws = c->ws; g.splitk_ws_floats = c->ws_floats;  // whatever else lives in ws was consumed by then (stream order)
+    return gemm_f32(&g, s);
+}
+
+// g <- [g +] dU W_i + dact_i w_out   (in place: every element is read and written by its own thread)
+static int bwd_block_dx_gemm(const dun_fc_ctx* c, int i, hipStream_t s) {
+    const int W = c->W;
+    dun_gemm_desc g;
     memset(&g, 0, sizeof(g));
     g.A = c->dU; g.lda = W; g.a_kcontig = 1;
     g.B = c->p.w + (size_t)i * W * W; g.ldb = W; g.b_kcontig = 0;
     g.C = c->G; g.ldc = W;
-    g.M = B; g.N = W; g.K = W;
+    g.M = c->B; g.N = W; g.K = W;
     if (c->residual) { g.R = c->G; g.ldr = W; }
-    g.U = c->dact + (size_t)i * B * c->O; g.V = c->p.w_out; g.O = c->O; g.ldv = W;
+    g.U = c->dact + (size_t)i * c->B * c->O; g.V = c->p.w_out; g.O = c->O; g.ldv = W;
     return gemm_f32(&g, s);
+}
+
+static int bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s) {
+    int rc = bwd_block_du(c, i, global_batch, s);
+    if (rc) return rc;
+    if ((rc = bwd_block_dw(c, i, s))) return rc;
+    return bwd_block_dx_gemm(c, i, s);
 }
 
 static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
@@ -651,6 +668,13 @@ extern "C" int dun_fc_head(const dun_fc_ctx* c, dun_stream_t stream) {
     int rc = check_ctx(c, "dun_fc_head");
     return rc ? rc : head(c, STREAM);
 }
+extern "C" int dun_fc_head_depth(const dun_fc_ctx* c, int d, dun_stream_t stream) {
+    int rc = check_ctx(c, "dun_fc_head_depth");
+    if (rc) return rc;
+    DUN_REQUIRE(d >= 0 && d <= c->depth, "dun_fc_head_depth: depth %d outside [0,%d]", d, c->depth);
+    return head_forward(c->H + (size_t)d * c->B * c->W, c->p.w_out, c->p.b_out, c->B, c->W, c->O,
+                        c->act + (size_t)d * c->B * c->O, STREAM);
+}
 extern "C" int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream) {
     int rc = check_ctx(c, "dun_fc_forward");
     if (rc) return rc;
@@ -682,6 +706,19 @@ extern "C" int dun_fc_bwd_block_apply(const dun_fc_ctx* c, int i, double global_
     if (rc) return rc;
     DUN_REQUIRE(i >= 0 && i < c->L, "dun_fc_bwd_block_apply: block %d outside [0,%d)", i, c->L);
     return bwd_block_apply(c, i, global_batch, STREAM);
+}
+extern "C" int dun_fc_bwd_block_dx(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream) {
+    int rc = check_bwd(c, "dun_fc_bwd_block_dx");
+    if (rc) return rc;
+    DUN_REQUIRE(i >= 0 && i < c->L, "dun_fc_bwd_block_dx: block %d outside [0,%d)", i, c->L);
+    if ((rc = bwd_block_du(c, i, global_batch, STREAM))) return rc;
+    return bwd_block_dx_gemm(c, i, STREAM);
+}
+extern "C" int dun_fc_bwd_block_dw(const dun_fc_ctx* c, int i, dun_stream_t stream) {
+    int rc = check_bwd(c, "dun_fc_bwd_block_dw");
+    if (rc) return rc;
+    DUN_REQUIRE(i >= 0 && i < c->L, "dun_fc_bwd_block_dw: block %d outside [0,%d)", i, c->L);
+    return bwd_block_dw(c, i, STREAM);
 }
 extern "C" int dun_fc_bwd_end(const dun_fc_ctx* c, dun_stream_t stream) {
     int rc = check_bwd(c, "dun_fc_bwd_end");

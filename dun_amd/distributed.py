@@ -10,10 +10,10 @@ is exchanged explicitly, and nothing else is:
     backward of the shallower blocks is still running, so the 16 MB-per-block messages overlap with the GEMMs.
 Everything travels on ONE communicator (collectives of one communicator execute in issue order on one stream; several
 communicators running concurrently are a known deadlock hazard when devices schedule their kernels in different
-orders).  The 16 KB BatchNorm exchange of block i-1 -- which the compute stream waits for -- must therefore not be
-issued behind the 16 MB gradient message of block i: the trunk backward issues the gradient message of block i only
-AFTER the BatchNorm exchange of block i-1 (see arq_uncert_fc_resnet._run_backward), when the next small message is
-a whole block of GEMMs away.
+orders).  In the trunk backward the BatchNorm exchange of block i-1 is asynchronous and the weight-gradient GEMM of
+block i runs underneath it (see arq_uncert_fc_resnet._run_backward); the 16 MB gradient message of block i is issued
+right behind that small exchange, so the NEXT small message -- which the compute stream will wait for -- is a dX GEMM,
+a BatchNorm reduction and a dW GEMM away from it.
 All ranks must hold the same number of rows (global batch = local batch * world size).
 """
 import torch
@@ -42,6 +42,13 @@ class Shard(object):
         if self.world > 1 or self.force_collectives:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def all_reduce_async(self, t):
+        """SUM all-reduce that the compute stream does not wait for yet: returns a handle (`.wait()` makes the current
+        stream wait for the result) or None when there is nothing to exchange."""
+        if self.world > 1 or self.force_collectives:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
 
     def reduce_gradient_async(self, t, exclude=None):
         """SUM all-reduce of a gradient slice; `exclude` is a sub-range of `t`'s storage that was already sent."""

@@ -174,6 +174,9 @@ class HipBackend(object):
     def fc_head(self, buf):
         self._fc("dun_fc_head", buf)
 
+    def fc_head_depth(self, buf, d):
+        self._fc("dun_fc_head_depth", buf, d)
+
     def fc_bwd_begin(self, buf):
         self._fc("dun_fc_bwd_begin", buf)
 
@@ -182,6 +185,12 @@ class HipBackend(object):
 
     def fc_bwd_block_apply(self, buf, i, global_batch):
         self._fc("dun_fc_bwd_block_apply", buf, i, float(global_batch))
+
+    def fc_bwd_block_dx(self, buf, i, global_batch):
+        self._fc("dun_fc_bwd_block_dx", buf, i, float(global_batch))
+
+    def fc_bwd_block_dw(self, buf, i):
+        self._fc("dun_fc_bwd_block_dw", buf, i)
 
     def fc_bwd_end(self, buf):
         self._fc("dun_fc_bwd_end", buf)

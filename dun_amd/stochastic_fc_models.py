@@ -212,13 +212,18 @@ class arq_uncert_fc_resnet(nn.Module):
         if dist is None or not (train and dist.sync_bn) or depth == 0:
             be.fc_forward(buf)
         else:
+            # the BatchNorm exchange of block i is asynchronous; the shared head on the hidden state the block started
+            # from (needed anyway, still in the Infinity Cache behind the GEMM that just read it) runs underneath it
             gb = dist.global_batch(x.shape[0])
             be.fc_input_layer(buf)
             for i in range(depth):
                 be.fc_block_linear(buf, i)
-                dist.all_reduce(buf.bn_sums)
+                h = dist.all_reduce_async(buf.bn_sums)
+                be.fc_head_depth(buf, i)
+                if h is not None:
+                    h.wait()
                 be.fc_block_norm(buf, i, gb)
-            be.fc_head(buf)
+            be.fc_head_depth(buf, depth)
         if train and depth > 0:
             self.num_batches_tracked[:depth] += 1
         return buf
@@ -233,20 +238,25 @@ class arq_uncert_fc_resnet(nn.Module):
         else:
             gb = dist.global_batch(buf.B)
             be.fc_bwd_begin(buf)
-            # The gradient message of block i is issued one stage late, right AFTER the BatchNorm exchange of block
-            # i-1: on the single communicator stream the small message the compute stream waits for is then never
-            # queued behind a 16 MB one (the next small message is a whole block of GEMMs away).
-            held = None
+            # The BatchNorm exchange of block i (16 KB, latency bound) sits between its column reduction and its dU;
+            # the weight-gradient GEMM of block i+1 needs neither, so it is deferred to run UNDER that exchange (dU of
+            # block i+1 stays in place until bwd_block_dx(i)).  The gradient message of block i+1 follows the small
+            # exchange on the single communicator stream and has a dX GEMM + a reduction + a dW GEMM of time before
+            # the next small message is queued behind it.
+            deferred = None
             for i in range(self.n_layers - 1, -1, -1):
                 be.fc_bwd_block_reduce(buf, i)
-                if dist.sync_bn:
-                    dist.all_reduce(buf.bn_sums)
-                if held is not None:
-                    dist.reduce_gradient_async(held)
-                be.fc_bwd_block_apply(buf, i, gb if dist.sync_bn else buf.B)
-                held = self.stacked_grad["w"][i]
-            if held is not None:
-                dist.reduce_gradient_async(held)
+                h = dist.all_reduce_async(buf.bn_sums) if dist.sync_bn else None
+                if deferred is not None:
+                    be.fc_bwd_block_dw(buf, deferred)
+                    dist.reduce_gradient_async(self.stacked_grad["w"][deferred])
+                if h is not None:
+                    h.wait()
+                be.fc_bwd_block_dx(buf, i, gb if dist.sync_bn else buf.B)
+                deferred = i
+            if deferred is not None:
+                be.fc_bwd_block_dw(buf, deferred)
+                dist.reduce_gradient_async(self.stacked_grad["w"][deferred])
             be.fc_bwd_end(buf)
             dist.reduce_gradient_async(self.flat_grads, exclude=self.stacked_grad["w"])
         for p, g in zip(self._param_list, self._grad_views):

@@ -180,14 +180,23 @@ int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream); /* whole net, nee
 
 /* The same work cut at the points where a batch-sharded job exchanges BatchNorm statistics:
  * forward:  input_layer; for i: block_linear(i) -> [all-reduce bn_sums] -> block_norm(i, global_batch); head
- * backward: bwd_begin; for i desc: bwd_block_reduce(i) -> [all-reduce bn_sums] -> bwd_block_apply(i, global_batch); bwd_end */
+ *           (head = head_depth(d) for d = 0..depth, row for row the same numbers: a sharded job runs head_depth(i),
+ *           which only needs the hidden state block i starts from, under the exchange of block i)
+ * backward: bwd_begin; for i desc: bwd_block_reduce(i) -> [all-reduce bn_sums] -> bwd_block_apply(i, global_batch); bwd_end
+ * bwd_block_apply(i) = bwd_block_dx(i) (dU_i, db_i, running gradient g <- [g +] dU_i W_i + dact_i w_out) followed by
+ * bwd_block_dw(i) (dW_i = dU_i^T H_i).  A sharded job calls the halves itself and runs bwd_block_dw(i) AFTER
+ * bwd_block_reduce(i-1), under the BatchNorm exchange of block i-1 (dU_i stays in place until bwd_block_dx(i-1)):
+ *   ... bwd_block_dx(i); bwd_block_reduce(i-1); [all-reduce in flight] bwd_block_dw(i); [wait] bwd_block_dx(i-1) ... */
 int dun_fc_input_layer(const dun_fc_ctx* c, dun_stream_t stream);
 int dun_fc_block_linear(const dun_fc_ctx* c, int i, dun_stream_t stream);
 int dun_fc_block_norm(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream);
 int dun_fc_head(const dun_fc_ctx* c, dun_stream_t stream);
+int dun_fc_head_depth(const dun_fc_ctx* c, int d, dun_stream_t stream);
 int dun_fc_bwd_begin(const dun_fc_ctx* c, dun_stream_t stream);
 int dun_fc_bwd_block_reduce(const dun_fc_ctx* c, int i, dun_stream_t stream);
 int dun_fc_bwd_block_apply(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream);
+int dun_fc_bwd_block_dx(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream);
+int dun_fc_bwd_block_dw(const dun_fc_ctx* c, int i, dun_stream_t stream);
 int dun_fc_bwd_end(const dun_fc_ctx* c, dun_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -170,6 +170,10 @@ class CpuBackend(object):
         p = buf.model.stacked
         buf.act.copy_(F.linear(buf.H, p["w_out"], p["b_out"]))
 
+    def fc_head_depth(self, buf, d):
+        p = buf.model.stacked
+        buf.act[d].copy_(F.linear(buf.H[d], p["w_out"], p["b_out"]))
+
     def fc_forward(self, buf):
         self.fc_input_layer(buf)
         for i in range(buf.depth):
@@ -192,7 +196,7 @@ class CpuBackend(object):
         g["beta"][i] = buf.bn_sums[0].float()
         g["gamma"][i] = buf.bn_sums[1].float()
 
-    def fc_bwd_block_apply(self, buf, i, global_batch):
+    def fc_bwd_block_dx(self, buf, i, global_batch):
         m, p, g = buf.model, buf.model.stacked, buf.model.stacked_grad
         z = buf.Z[i]
         xh = (z - buf.bn_mean[i]) * buf.bn_rstd[i]
@@ -200,9 +204,15 @@ class CpuBackend(object):
         dU = (z > 0).float() * (p["gamma"][i] * buf.bn_rstd[i]) * (buf.G - mg - xh * mgx)
         buf.dU.copy_(dU)
         g["b"][i] = dU.sum(0)
-        g["w"][i] = dU.t() @ buf.H[i]
         new = dU @ p["w"][i] + buf.dact[i] @ p["w_out"]
         buf.G.copy_(buf.G + new if m.residual else new)
+
+    def fc_bwd_block_dw(self, buf, i):
+        buf.model.stacked_grad["w"][i] = buf.dU.t() @ buf.H[i]
+
+    def fc_bwd_block_apply(self, buf, i, global_batch):
+        self.fc_bwd_block_dx(buf, i, global_batch)
+        self.fc_bwd_block_dw(buf, i)
 
     def fc_bwd_end(self, buf):
         g = buf.model.stacked_grad

@@ -274,6 +274,13 @@ def test_sharded_path_world1_matches_unsharded():
         quiet(shard, net, sync_bn=True)
         got = [net.fit(x, y) for _ in range(2)]
         assert np.allclose(got, want, rtol=1e-6)
+        # the same two steps with every collective of the N-GPU step ISSUED on the one-rank communicator: asynchronous
+        # BatchNorm exchange with the deferred dW GEMM underneath, per-block gradient messages, likelihood sums
+        net2 = build_net(c)
+        quiet(shard, net2, sync_bn=True).force_collectives = True
+        got2 = [net2.fit(x, y) for _ in range(2)]
+        assert np.allclose(got2, want, rtol=1e-6)
+        assert torch.equal(net2.model.flat_params, net.model.flat_params)
         # the collectives the N-GPU path issues, through RCCL itself (Shard skips them at world size 1): fp64 SUM,
         # asynchronous SUM on a slice of the flat gradient buffer, MAX, broadcast, barrier
         t = torch.arange(128, dtype=torch.float64, device="cuda").view(2, 64)
