@@ -6,12 +6,12 @@ is exchanged explicitly, and nothing else is:
   * BatchNorm batch statistics: fp64 [2,W] sums per block, forward and backward (``sync_bn=True`` reproduces the
     single-device numerics of the full batch; ``False`` gives per-replica statistics like DataParallel would);
   * the per-depth likelihood sums: one fp64 [D] all-reduce per step (the VI backward does not wait for it);
-  * parameter gradients: SUM all-reduce (the loss already carries 1/global_batch), issued per block while the
-    backward of the shallower blocks is still running, so the 16 MB-per-block messages overlap with the GEMMs.
+  * parameter gradients: SUM all-reduce (the loss already carries 1/global_batch), issued per bucket of two blocks
+    while the backward of the shallower blocks is still running, so the 2 x 16 MB messages overlap with the GEMMs.
 Everything travels on ONE communicator (collectives of one communicator execute in issue order on one stream; several
 communicators running concurrently are a known deadlock hazard when devices schedule their kernels in different
 orders).  In the trunk backward the BatchNorm exchange of block i-1 is asynchronous and the weight-gradient GEMM of
-block i runs underneath it (see arq_uncert_fc_resnet._run_backward); the 16 MB gradient message of block i is issued
+block i runs underneath it (see arq_uncert_fc_resnet._run_backward); the gradient message that block i completes (two blocks, 33 MB) is issued
 right behind that small exchange, so the NEXT small message -- which the compute stream will wait for -- is a dX GEMM,
 a BatchNorm reduction and a dW GEMM away from it.
 All ranks must hold the same number of rows (global batch = local batch * world size).
@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 
 class Shard(object):
-    def __init__(self, group=None, sync_bn=True, overlap=True):
+    def __init__(self, group=None, sync_bn=True, overlap=True, grad_bucket_blocks=2):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -31,6 +31,7 @@ class Shard(object):
         self.overlap = overlap
         self._pending = []
         self.grad_group = group
+        self.grad_bucket_blocks = max(1, int(grad_bucket_blocks))  # blocks per weight-gradient message (W*W floats each)
         # rehearsal switch (scripts/shard_rehearsal.py): issue every collective even in a one-rank group, so the
         # stream hand-offs, async handles and message order of the N-GPU step run on a one-GPU box
         self.force_collectives = False
@@ -72,9 +73,9 @@ class Shard(object):
         self._pending = []
 
 
-def shard(net, group=None, sync_bn=True, overlap=True):
+def shard(net, group=None, sync_bn=True, overlap=True, grad_bucket_blocks=2):
     """Make a DUN / DUN_VI wrapper train on this rank's shard of every global batch."""
-    spec = Shard(group, sync_bn=sync_bn, overlap=overlap)
+    spec = Shard(group, sync_bn=sync_bn, overlap=overlap, grad_bucket_blocks=grad_bucket_blocks)
     # replicas must start identical: rank 0's parameters, BatchNorm buffers, q_logits and log_std win
     with torch.no_grad():
         tensors = [p.data for p in net.model.parameters() if getattr(p, "_dun_flat_owner", None) is None]

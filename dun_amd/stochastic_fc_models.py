@@ -243,20 +243,29 @@ class arq_uncert_fc_resnet(nn.Module):
             # block i+1 stays in place until bwd_block_dx(i)).  The gradient message of block i+1 follows the small
             # exchange on the single communicator stream and has a dX GEMM + a reduction + a dW GEMM of time before
             # the next small message is queued behind it.
+            # Weight gradients leave in buckets of `dist.grad_bucket_blocks` consecutive blocks (one contiguous slice
+            # of the stacked gradient): fewer, larger messages for the per-link-bound xGMI rings.
             deferred = None
+            sent_from = self.n_layers  # blocks [sent_from, L) are on their way
+
+            def dw_and_send(j):
+                nonlocal sent_from
+                be.fc_bwd_block_dw(buf, j)
+                if sent_from - j >= dist.grad_bucket_blocks or j == 0:
+                    dist.reduce_gradient_async(self.stacked_grad["w"][j:sent_from])
+                    sent_from = j
+
             for i in range(self.n_layers - 1, -1, -1):
                 be.fc_bwd_block_reduce(buf, i)
                 h = dist.all_reduce_async(buf.bn_sums) if dist.sync_bn else None
                 if deferred is not None:
-                    be.fc_bwd_block_dw(buf, deferred)
-                    dist.reduce_gradient_async(self.stacked_grad["w"][deferred])
+                    dw_and_send(deferred)
                 if h is not None:
                     h.wait()
                 be.fc_bwd_block_dx(buf, i, gb if dist.sync_bn else buf.B)
                 deferred = i
             if deferred is not None:
-                be.fc_bwd_block_dw(buf, deferred)
-                dist.reduce_gradient_async(self.stacked_grad["w"][deferred])
+                dw_and_send(deferred)
             be.fc_bwd_end(buf)
             dist.reduce_gradient_async(self.flat_grads, exclude=self.stacked_grad["w"])
         for p, g in zip(self._param_list, self._grad_views):

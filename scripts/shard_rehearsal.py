@@ -16,8 +16,8 @@ din, W, L, B, N_train, lr, mom, wd = bench.WORKLOADS["c3_wide"]
 for N in ([int(a) for a in sys.argv[1:]] or [8, 4, 2, 1]):
     Bl = B // N
     for sharded in (False, True, "coll", "coll-localbn"):
-        if N == 1 and sharded == "coll-localbn":
-            continue
+        if N == 1 and sharded in ("coll", "coll-localbn"):
+            continue  # a one-GPU job has no collectives
         net = bench.build_net(din, W, L, N_train, lr, mom, wd)
         if sharded:
             # "coll-localbn": per-replica BatchNorm statistics, i.e. only the gradient messages and the likelihood sums
