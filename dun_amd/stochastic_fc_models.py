@@ -28,12 +28,20 @@ class _FcForward(torch.autograd.Function):
     def forward(ctx, model, x, depth, *params):
         buf = model._run_forward(x, depth, True)
         ctx.model, ctx.buf = model, buf
-        return buf.act
+        # The returned tensor becomes this node's output (grad_fn -> node -> parameters -> model).  Left in the buffer
+        # object it would close model -> buffers -> act -> node -> model through the C++ autograd graph, which
+        # Python's collector cannot see: a dropped model kept its activation buffers (55 GB at C3) allocated.
+        act, buf.act = buf.act, None
+        return act
 
     @staticmethod
     def backward(ctx, dact):
-        ctx.model._run_backward(ctx.buf, dact)
-        return (None, None, None) + (None,) * len(ctx.model._param_list)
+        model, buf = ctx.model, ctx.buf
+        if buf is None:
+            raise RuntimeError("the trunk's backward ran already (its buffers are reused by the next forward)")
+        ctx.model = ctx.buf = None  # a kept act_vec does not pin the buffers
+        model._run_backward(buf, dact)
+        return (None, None, None) + (None,) * len(model._param_list)
 
 
 class arq_uncert_fc_resnet(nn.Module):

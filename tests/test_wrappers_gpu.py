@@ -303,6 +303,28 @@ def test_sharded_path_world1_matches_unsharded():
         dist.destroy_process_group()
 
 
+def test_discarded_net_releases_its_buffers(monkeypatch):
+    """model -> buffers -> act_vec -> grad_fn -> parameters -> model would be a cycle through the C++ autograd graph
+    (invisible to Python's collector); the buffers do not keep the autograd output, so a trained-and-dropped net gives
+    its activation memory back."""
+    import gc
+    monkeypatch.setenv("DUN_NO_GRAPH", "1")
+    c = Case("c3_reduced")
+    x, y = c.t("x").cuda(), c.y().cuda()
+    gc.collect()
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    net = build_net(c)
+    net.fit(x, y)
+    net.fit(x, y)
+    held = torch.cuda.memory_allocated() - before
+    del net
+    gc.collect()
+    torch.cuda.synchronize()
+    left = torch.cuda.memory_allocated() - before
+    assert held > 0 and left < 0.05 * held, (held, left)
+
+
 @pytest.mark.parametrize("name", ["c2_boston", "cls_fc", "mll_small"])
 def test_graphed_step_is_bit_identical_to_eager(name, monkeypatch):
     """The whole-step hipGraph (captured on the 2nd call) must reproduce the eager launch sequence exactly, also
