@@ -448,8 +448,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmP p) {
 //               DMA half j+3 -> stage (j+3)&3 (the stage of half j-1)
 //               [read frags (j+1, group 0)]  16 MFMAs (j, group 1)
 // so no wave ever crosses a tile boundary with nothing to issue.  Images: K-contiguous [128][16] (64-B rows, 16-B chunk
-// index XOR (row>>1)&3 on the source address and on the read), M/N-contiguous [16][128].
+// index XOR (row>>2)&3 on the source address and on the read: 16 consecutive rows of one chunk column then cover all
+// 16 chunk slots of the 256-byte bank line -- rows r, r+4, r+8, r+12 share (row&3) and differ in (row>>2)&3; with
+// (row>>1)&3 rows r and r+8 collided, 2.9 % of the forward GEMM's wave cycles), M/N-contiguous [16][128].
 // ---------------------------------------------------------------------------------------------------------
+#ifndef DUN_KC_SWZ_SHIFT
+#define DUN_KC_SWZ_SHIFT 2  // A/B builds: -DDUN_KC_SWZ_SHIFT=1 is the first version's swizzle
+#endif
 constexpr int HK = 16;                 // K depth of a half tile
 constexpr int HALF_TILE = BM * HK;     // 2048 floats = 8 KiB per operand
 constexpr int STAGE = 2 * HALF_TILE;   // A image | B image
@@ -475,7 +480,7 @@ __device__ __forceinline__ DmaOp dma_setup(const float* P, int ld, int r0, int r
         const int piece = wave * 2 + j;
         if (KC) {
             const int row = piece * 16 + (lane >> 2), pc = lane & 3;
-            const int c = pc ^ ((row >> 1) & 3);
+            const int c = pc ^ ((row >> DUN_KC_SWZ_SHIFT) & 3);
             d.voff[j] = ((r0 + row) * ld + c * 4) * 4;
         } else {
             const int k = piece * 2 + (lane >> 5), col = (lane & 31) * 4;
@@ -498,7 +503,7 @@ __device__ __forceinline__ void dma_half(const DmaOp& d, int k0, float* lds, int
 template <bool KC>
 __device__ __forceinline__ void read_frag_half(const float* lds, int row, int t, int h, float (&f)[4]) {
     if (KC) {
-        const int pc = (2 * t + h) ^ ((row >> 1) & 3);
+        const int pc = (2 * t + h) ^ ((row >> DUN_KC_SWZ_SHIFT) & 3);
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * HK + pc * 4);
         f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
     } else {
