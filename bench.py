@@ -278,7 +278,18 @@ def cpu_baseline(din, W, L, N_train, lr, momentum, wd, B_cpu):
                        "%.2f s/step, throughput scaled per sample" % (steps, B_cpu, dt))
 
 
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner to fd 1 when
+    its first communicator comes up), so fd 1 is pointed at stderr for the whole run and the line goes to the original
+    stdout, returned here as a file object."""
+    sys.stdout.flush()
+    out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return out
+
+
 def main():
+    json_out = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -288,6 +299,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0)
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="one-GPU rehearsal of the N>1 branch of this script: a one-rank RCCL group, the sharded step "
+                         "with every collective issued, the barriers and the MAX-over-ranks timing")
     ap.add_argument("--predict", action="store_true",
                     help="time DUN_VI.predict(x, get_std=True) (eval-mode forward + depth-marginal predictor) instead "
                          "of fit; prints the same JSON line with metric 'DUN predict samples/sec'")
@@ -314,10 +328,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DUN kernels have no CPU path")
     torch.cuda.set_device(local_rank)
-    dist_on = world > 1
+    dist_on = world > 1 or args.rehearse_dist
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rehearse_dist:
+            for k, v in (("MASTER_PORT", "29541"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert B % world == 0
     B_local = B // world
@@ -336,7 +353,8 @@ def main():
         x, y = shard_data(B_local, din, rank, torch.device("cuda", local_rank))
     if dist_on:
         from dun_amd.distributed import shard
-        shard(net, sync_bn=not args.no_sync_bn)
+        spec = shard(net, sync_bn=not args.no_sync_bn)
+        spec.force_collectives = bool(args.rehearse_dist)
 
     def barrier():
         torch.cuda.synchronize()
@@ -368,7 +386,7 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "%s: predict, global batch %d (%d rows/GPU)" % (args.workload, B, B_local),
-                           "parallelism": "dp%d batch-sharded (no collective: eval-mode BatchNorm)" % world}}), flush=True)
+                           "parallelism": "dp%d batch-sharded (no collective: eval-mode BatchNorm)" % world}}), file=json_out, flush=True)
         if dist_on:
             dist.barrier()
             dist.destroy_process_group()
@@ -410,7 +428,7 @@ def main():
             result["roofline_other_kernels"] = {
                 k: {"bound": "hbm", "achieved": v["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": v["gbs"] / HBM_PEAK_GBS, "ms_per_launch": v["ms"]} for k, v in kr.items()}
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=json_out, flush=True)
     if image:
         if dist_on:
             dist.barrier()
@@ -454,7 +472,7 @@ def main():
         B_cpu = args.cpu_batch or (2048 if args.workload == "c3_wide" else B)
         result["cpu_baseline"] = cpu_baseline(din, W, L, N_train, lr, momentum, wd, B_cpu)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=json_out, flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
