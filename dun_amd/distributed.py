@@ -11,8 +11,9 @@ is exchanged explicitly, and nothing else is:
 Everything travels on ONE communicator (collectives of one communicator execute in issue order on one stream; several
 communicators running concurrently are a known deadlock hazard when devices schedule their kernels in different
 orders).  In the trunk backward the BatchNorm exchange of block i-1 is asynchronous and the weight-gradient GEMM of
-block i runs underneath it (see arq_uncert_fc_resnet._run_backward); the gradient message that block i completes (two blocks, 33 MB) is issued
-right behind that small exchange, so the NEXT small message -- which the compute stream will wait for -- is a dX GEMM,
+block i runs underneath it (see arq_uncert_fc_resnet._run_backward); the forward exchanges are synchronous (nothing
+worth hiding under them).  The gradient message that block i completes (two blocks, 33 MB) is issued right behind
+that small backward exchange, so the NEXT small message -- which the compute stream will wait for -- is a dX GEMM,
 a BatchNorm reduction and a dW GEMM away from it.
 All ranks must hold the same number of rows (global batch = local batch * world size).
 """
@@ -32,6 +33,9 @@ class Shard(object):
         self._pending = []
         self.grad_group = group
         self.grad_bucket_blocks = max(1, int(grad_bucket_blocks))  # blocks per weight-gradient message (W*W floats each)
+        # forward BatchNorm exchange asynchronous too (only the 12 us per-depth head can run underneath it, less than
+        # the two extra stream hand-offs cost on a one-rank communicator: off unless measured otherwise on 8 GPUs)
+        self.async_forward_bn = False
         # rehearsal switch (scripts/shard_rehearsal.py): issue every collective even in a one-rank group, so the
         # stream hand-offs, async handles and message order of the N-GPU step run on a one-GPU box
         self.force_collectives = False

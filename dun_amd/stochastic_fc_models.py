@@ -220,16 +220,20 @@ class arq_uncert_fc_resnet(nn.Module):
         if dist is None or not (train and dist.sync_bn) or depth == 0:
             be.fc_forward(buf)
         else:
-            # the BatchNorm exchange of block i is asynchronous; the shared head on the hidden state the block started
-            # from (needed anyway, still in the Infinity Cache behind the GEMM that just read it) runs underneath it
+            # the shared head runs depth by depth on the hidden state block i started from (still in the Infinity Cache
+            # behind the GEMM that just read it); with dist.async_forward_bn it runs UNDER the exchange of block i
             gb = dist.global_batch(x.shape[0])
             be.fc_input_layer(buf)
             for i in range(depth):
                 be.fc_block_linear(buf, i)
-                h = dist.all_reduce_async(buf.bn_sums)
-                be.fc_head_depth(buf, i)
-                if h is not None:
-                    h.wait()
+                if dist.async_forward_bn:
+                    h = dist.all_reduce_async(buf.bn_sums)
+                    be.fc_head_depth(buf, i)
+                    if h is not None:
+                        h.wait()
+                else:
+                    dist.all_reduce(buf.bn_sums)
+                    be.fc_head_depth(buf, i)
                 be.fc_block_norm(buf, i, gb)
             be.fc_head_depth(buf, depth)
         if train and depth > 0:

@@ -15,14 +15,15 @@ din, W, L, B, N_train, lr, mom, wd = bench.WORKLOADS["c3_wide"]
 # usage: shard_rehearsal.py [N ...]   (default 8 4 2 1)
 for N in ([int(a) for a in sys.argv[1:]] or [8, 4, 2, 1]):
     Bl = B // N
-    for sharded in (False, True, "coll", "coll-localbn"):
-        if N == 1 and sharded in ("coll", "coll-localbn"):
+    for sharded in (False, True, "coll", "coll-asyncfwd", "coll-localbn"):
+        if N == 1 and sharded in ("coll", "coll-asyncfwd", "coll-localbn"):
             continue  # a one-GPU job has no collectives
         net = bench.build_net(din, W, L, N_train, lr, mom, wd)
         if sharded:
             # "coll-localbn": per-replica BatchNorm statistics, i.e. only the gradient messages and the likelihood sums
             spec = shard(net, sync_bn=sharded != "coll-localbn")
-            spec.force_collectives = sharded in ("coll", "coll-localbn")
+            spec.force_collectives = sharded in ("coll", "coll-asyncfwd", "coll-localbn")
+            spec.async_forward_bn = sharded == "coll-asyncfwd"
         x, y = bench.shard_data(Bl, din, 0, torch.device("cuda"))
         for _ in range(2):
             net.fit(x, y)
@@ -33,8 +34,8 @@ for N in ([int(a) for a in sys.argv[1:]] or [8, 4, 2, 1]):
         t0 = time.perf_counter()
         net.fit(x, y)
         host = time.perf_counter() - t0   # time until fit returns (includes the metrics D2H sync)
-        print("N=%d local batch %6d %-22s %.2f ms/step  (ideal-scaling throughput %.0f samples/s)" %
-              (N, Bl, {False: "fused", True: "staged", "coll": "staged+coll", "coll-localbn": "staged+coll, local BN"}[sharded], dt * 1e3, B / dt), flush=True)
+        print("N=%d local batch %6d %-26s %.2f ms/step  (ideal-scaling throughput %.0f samples/s)" %
+              (N, Bl, {False: "fused", True: "staged", "coll": "staged+coll", "coll-asyncfwd": "staged+coll, async fwd BN", "coll-localbn": "staged+coll, local BN"}[sharded], dt * 1e3, B / dt), flush=True)
         del net
         gc.collect()  # (module <-> buffer cycles: without it the 55 GB of the previous variant stay allocated)
         torch.cuda.empty_cache()
