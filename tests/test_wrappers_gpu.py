@@ -281,6 +281,11 @@ def test_sharded_path_world1_matches_unsharded():
         got2 = [net2.fit(x, y) for _ in range(2)]
         assert np.allclose(got2, want, rtol=1e-6)
         assert torch.equal(net2.model.flat_params, net.model.flat_params)
+        net3 = build_net(c)  # forward exchanges asynchronous as well (off by default)
+        spec3 = quiet(shard, net3, sync_bn=True)
+        spec3.force_collectives = spec3.async_forward_bn = True
+        assert np.allclose([net3.fit(x, y) for _ in range(2)], want, rtol=1e-6)
+        assert torch.equal(net3.model.flat_params, net.model.flat_params)
         # the collectives the N-GPU path issues, through RCCL itself (Shard skips them at world size 1): fp64 SUM,
         # asynchronous SUM on a slice of the flat gradient buffer, MAX, broadcast, barrier
         t = torch.arange(128, dtype=torch.float64, device="cuda").view(2, 64)
