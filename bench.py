@@ -24,11 +24,20 @@ import time
 # mode picks from its heuristics instead (set before MIOpen loads; an explicit setting wins)
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
-import torch  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# torch is imported by the ranks only (import_torch(), called from run_rank): the parent of a self-launched N-rank job
+# starts the ranks as child processes and must never initialise the GPU itself
+torch = None
+
+
+def import_torch():
+    global torch
+    import torch as _torch
+    torch = _torch
+    return _torch
 
 # MI355X peaks (MI355X_MICROARCH.md): HBM3E 8 TB/s; dense fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s
 HBM_PEAK_GBS = 8000.0
@@ -288,8 +297,7 @@ def _claim_stdout():
     return out
 
 
-def main():
-    json_out = _claim_stdout()
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -302,6 +310,12 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="one-GPU rehearsal of the N>1 branch of this script: a one-rank RCCL group, the sharded step "
                          "with every collective issued, the barriers and the MAX-over-ranks timing")
+    ap.add_argument("--cpu-rehearsal", action="store_true",
+                    help="TEST SEAM, not a measurement: run the launch / rendezvous / sharded-step / JSON plumbing of "
+                         "this script on CPU ranks (gloo) with the tests' stand-in backend (tests/cpu_backend.py) on a "
+                         "tiny net; the line it prints is labelled as a rehearsal")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launched N-rank job: seconds after which the parent ends ranks that are still running")
     ap.add_argument("--predict", action="store_true",
                     help="time DUN_VI.predict(x, get_std=True) (eval-mode forward + depth-marginal predictor) instead "
                          "of fit; prints the same JSON line with metric 'DUN predict samples/sec'")
@@ -311,7 +325,89 @@ def main():
     ap.add_argument("--channels-last", action="store_true",
                     help="image workloads: NHWC conv trunk; the head/ELBO path is unaffected (measured SLOWER with MIOpen's "
                          "immediate mode on fp32: 13.0 s vs 2.85 s per c5_cifar step -- off by default)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this same script (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set),
+    relay rank 0's JSON line, and fail if any rank fails.  This parent process never imports torch or touches a GPU."""
+    import subprocess
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DUN_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one JSON line comes from rank 0's stdout; what the other ranks might print there goes to our stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    deadline = time.time() + args.launch_timeout
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        if live and failed is None:
+            if time.time() > deadline:
+                failed = (min(live), "timeout after %.0f s" % args.launch_timeout)
+                break
+            time.sleep(0.2)
+    if failed is not None:
+        for r in sorted(live):  # the exact processes started above, nothing else
+            procs[r].terminate()
+        t_end = time.time() + 20
+        for r in sorted(live):
+            try:
+                procs[r].wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        print("bench.py: rank %d of %d failed (%s); no result" % (failed[0], n, failed[1]), file=sys.stderr, flush=True)
+        return 1
+    out = procs[0].stdout.read().decode()
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
+    if len(lines) != 1:
+        print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr, flush=True)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.rehearse_dist:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
+
+
+def run_rank(args):
+    json_out = _claim_stdout()
+    import_torch()
+    cpu = bool(args.cpu_rehearsal)
+    if cpu:
+        from dun_amd import kernels
+        from tests.cpu_backend import CpuBackend
+        kernels.set_backend(CpuBackend())
+        WORKLOADS["cpu_rehearsal"] = (8, 32, 3, 64, 1 << 10, 1e-3, 0.5, 0.0)
+        args.workload = "cpu_rehearsal"
+        args.no_kernel_rooflines = args.no_cpu_baseline = True
 
     image = args.workload in IMAGE_WORKLOADS
     if image:
@@ -322,22 +418,43 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the DUN kernels have no CPU path")
-    torch.cuda.set_device(local_rank)
+    if args.gpus != world and not args.rehearse_dist:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d in the environment" % (args.gpus, world))
+    if cpu:
+        device = torch.device("cpu")
+        torch.set_num_threads(2)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the DUN kernels have no CPU path")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist_on = world > 1 or args.rehearse_dist
+    world_formed = ranks_counted = 1
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_dist:
             for k, v in (("MASTER_PORT", "29541"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(k, v)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if cpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        # did the communicator really form over N ranks?  its own size, and a SUM all-reduce of ones over the wire
+        world_formed = dist.get_world_size()
+        ones = torch.ones(1, device=device, dtype=torch.float64)
+        dist.all_reduce(ones)
+        ranks_counted = int(round(float(ones.item())))
+        if world_formed != world or ranks_counted != world:
+            raise SystemExit("bench.py: asked for %d ranks, the communicator has %d and counted %d" % (world, world_formed, ranks_counted))
     assert B % world == 0
     B_local = B // world
+
+    def dev_sync():
+        if not cpu:
+            torch.cuda.synchronize()
 
     if image:
         net = build_image_net(channels, N_train)
@@ -349,18 +466,24 @@ def main():
             x = x.contiguous(memory_format=torch.channels_last)
         y = torch.randint(0, 10, (B_local,), generator=g).cuda()
     else:
-        net = build_net(din, W, L, N_train, lr, momentum, wd)
-        x, y = shard_data(B_local, din, rank, torch.device("cuda", local_rank))
+        net = build_net(din, W, L, N_train, lr, momentum, wd, cuda=not cpu)
+        x, y = shard_data(B_local, din, rank, device)
     if dist_on:
         from dun_amd.distributed import shard
         spec = shard(net, sync_bn=not args.no_sync_bn)
         spec.force_collectives = bool(args.rehearse_dist)
 
     def barrier():
-        torch.cuda.synchronize()
+        dev_sync()
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
+
+    def dist_fields():
+        return {"world_size_formed": world_formed, "ranks_counted_by_allreduce": ranks_counted,
+                "launcher": "self (bench.py started the ranks)" if os.environ.get("DUN_BENCH_SELF_LAUNCHED") else
+                            ("torch.distributed.run / external" if world > 1 else "single process"),
+                "backend": (dist.get_backend() if dist_on else None)}
 
     if args.predict:
         step = (lambda: net.predict(x, get_std=True)) if not image else (lambda: net.predict(x))
@@ -374,7 +497,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist_on:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         first = out[0] if isinstance(out, tuple) else out
@@ -386,7 +509,8 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "%s: predict, global batch %d (%d rows/GPU)" % (args.workload, B, B_local),
-                           "parallelism": "dp%d batch-sharded (no collective: eval-mode BatchNorm)" % world}}), file=json_out, flush=True)
+                           "parallelism": "dp%d batch-sharded (no collective: eval-mode BatchNorm)" % world,
+                           "distributed": dist_fields()}}), file=json_out, flush=True)
         if dist_on:
             dist.barrier()
             dist.destroy_process_group()
@@ -396,7 +520,7 @@ def main():
     for i in range(args.warmup):
         last = net.fit(x, y)
         if image and rank == 0:
-            torch.cuda.synchronize()
+            dev_sync()
             print("[bench] warm-up step %d done" % i, file=sys.stderr, flush=True)
     barrier()
     t0 = time.perf_counter()
@@ -405,7 +529,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if not all(math.isfinite(v) for v in last):
@@ -422,7 +546,7 @@ def main():
                                    "10 classes) on %dx%dx%d inputs, global batch %d (%d/GPU), conv trunk on MIOpen, "
                                    "head + CE/ELBO on the HIP kernels" % (args.workload, channels, side, side, B, B_local),
                        "parallelism": "dp%d batch-sharded, per-replica BatchNorm2d" % world,
-                       "train_metrics_last_step": list(last)}}
+                       "distributed": dist_fields(), "train_metrics_last_step": list(last)}}
         if not args.no_kernel_rooflines:
             kr = image_head_rooflines(net, B_local)
             result["roofline_other_kernels"] = {
@@ -446,9 +570,14 @@ def main():
                                    "%d (%d rows/GPU), N_train %d, SGD(lr %g, momentum %g)" %
                                    (args.workload, L, W, din, B, B_local, N_train, lr, momentum),
                        "parallelism": "dp%d batch-sharded, %s BatchNorm" % (world, "per-replica" if args.no_sync_bn and dist_on else "synchronised" if dist_on else "single-device"),
+                       "distributed": dist_fields(),
                        "step_tflop": flop_step / 1e12, "train_metrics_last_step": list(last)},
             "step_tflops_per_gpu": flop_step / world / (ms_step / 1e3) / 1e12,
         }
+        if cpu:  # never to be mistaken for a measurement
+            result["metric"] = "REHEARSAL ONLY (CPU ranks, gloo, tests/cpu_backend.py stand-in): not a DUN_AMD measurement"
+            result["data"] = "synthetic, tiny; CPU rehearsal of the launch path"
+            result["dtype"] = "f32 (torch CPU stand-in)"
     if rank == 0 and not args.no_kernel_rooflines:
         kr = kernel_rooflines(net, B_local, reps=5 if args.workload == "c3_wide" else 20)
         # dominant kernel of the step: the trunk GEMM (3*L launches per step); quote the forward instantiation
