@@ -19,6 +19,23 @@ from . import kernels
 from ._lib import OBJ_MLL, OBJ_VI, RES_DLOG_STD, RES_E_LOGLIKE, RES_HEADER, RES_KL, RES_LOG_MARG, RES_OBJECTIVE
 
 
+class diag_w_Gauss_loglike(object):
+    """Factorised Gaussian weight prior of the reference's regression experiments (src/probability.py:30-40):
+    ``prior(w)`` = multiplier * sum log N(w; mu, scale).  As in the reference the second argument, although named
+    sigma^2, is used as the SCALE (standard deviation) of the Normal.  An O(#parameters) torch reduction evaluated
+    once per step on the replicated weights -- not part of the per-sample path."""
+
+    def __init__(self, μ=0, σ2=1, multiplier=1):
+        self.μ, self.σ2, self.multiplier = μ, σ2, multiplier
+        self._const = -float(np.log(σ2)) - 0.5 * float(np.log(2 * np.pi))
+
+    def __call__(self, w):
+        return (self._const * w.numel() - ((w - self.μ) ** 2).sum() / (2 * self.σ2 ** 2)) * self.multiplier
+
+    def summary(self):
+        return {"name": "diag_w_Gauss", "μ": self.μ, "σ2": self.σ2, "mul": self.multiplier}
+
+
 class homo_Gauss_mloglike(nn.Module):
     """Homoscedastic Gaussian negative log-likelihood with a learnable (or fixed) log std."""
 
@@ -121,11 +138,21 @@ def _fused(act_vec, y, f_neg_loglike, N_train, logprior, prior_loglikes, objecti
     return out
 
 
+def _autograd_route_is_single_device(dist, act_vec):
+    """The differentiable reference-named entries (estimate_ELBO / get_w_joint_loglike + loss.backward()) leave the
+    gradient exchange of a sharded job to nobody: only fit() orders trunk backward -> all-reduce -> wait -> prior
+    gradient -> step.  Refuse instead of training replicas apart."""
+    if dist is not None and dist.world > 1 and act_vec.requires_grad:
+        raise RuntimeError("batch-sharded job: differentiate through net.fit(), not through estimate_ELBO / "
+                           "get_w_joint_loglike + backward() (nothing would wait for the gradient all-reduce)")
+
+
 class _JointLoglike(torch.autograd.Function):
     """joint[d] = (N/B) sum_b loglike[d,b] + prior[d], differentiable w.r.t. act_vec, log_std and the prior."""
 
     @staticmethod
     def forward(ctx, act_vec, log_std, prior, y, f_neg_loglike, N_train, dist):
+        _autograd_route_is_single_device(dist, act_vec)
         D = act_vec.shape[0]
         out = _fused(act_vec, y, f_neg_loglike, N_train, torch.zeros(D), prior, OBJ_MLL, want_grad=False, dist=dist)
         ctx.save_for_backward(act_vec, y, out.sums)
@@ -222,6 +249,7 @@ class _Elbo(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, act_vec, q_logits, log_std, prior, y, f_neg_loglike, N_train, pm, beta):
+        _autograd_route_is_single_device(pm._dist, act_vec)
         out = _fused(act_vec, y, f_neg_loglike, N_train, pm.logprior, prior, OBJ_VI, q_logits=q_logits, beta=beta,
                      eps=pm.eps, want_grad=True, dist=pm._dist)
         ctx.save_for_backward(out.dact, out.res)

@@ -14,17 +14,8 @@ import time
 import numpy as np
 import torch
 
+from ._epochs import QWarmup, epoch_means
 from .utils import cprint, mkdir
-
-
-def _epoch_means(loader, step, flat_ims, width):
-    """Row-weighted means of whatever ``step(x, y)`` returns (a ``width``-tuple of floats) over one pass."""
-    sums, rows = np.zeros(width), 0
-    for x, y in loader:
-        xb = x.view(x.shape[0], -1) if flat_ims else x
-        sums += np.asarray(step(xb, y), dtype=np.float64) * xb.shape[0]
-        rows += len(xb)
-    return sums / max(rows, 1)
 
 
 class _RunLog(object):
@@ -64,20 +55,17 @@ def train_fc_DUN(net, name, save_dir, batch_size, nb_epochs, train_loader, val_l
             torch.cuda.manual_seed(seed)
 
     log = _RunLog(nb_epochs)
-    q_logits = net.prob_model.q_logits
-    if q_nograd_its > 0:
-        q_logits.requires_grad = False
+    warmup = QWarmup(net.prob_model, q_nograd_its)
     best_value, best_epoch, epochs_run = -np.inf, 0, 0
     started = time.time()
 
     for ep in range(nb_epochs):
         epochs_run = ep + 1
-        if q_nograd_its > 0 and ep == q_nograd_its:
-            q_logits.requires_grad = True
+        warmup.at_epoch(ep)
 
         net.set_mode_train(True)
         t0 = time.time()
-        log.objective[ep], log.train_nll[ep], log.train_err[ep] = _epoch_means(train_loader, net.fit, flat_ims, 3)
+        log.objective[ep], log.train_nll[ep], log.train_err[ep] = epoch_means(train_loader, net.fit, 3, flat_ims)
         q_now = net.prob_model.current_posterior.data.cpu().numpy()
         print("\n depth approx posterior", q_now)
         print("it %d/%d, ELBO/evidence %.4f, pred minus loglike = %f, err = %f"
@@ -95,7 +83,7 @@ def train_fc_DUN(net, name, save_dir, batch_size, nb_epochs, train_loader, val_l
 
         if ep % nb_its_dev == 0:
             t0 = time.time()
-            log.dev_nll[ep], log.dev_err[ep] = _epoch_means(val_loader, net.eval, flat_ims, 2)
+            log.dev_nll[ep], log.dev_err[ep] = epoch_means(val_loader, net.eval, 2, flat_ims)
             cprint("g", "     pred minus loglike = %f, err = %f\n" % (log.dev_nll[ep], log.dev_err[ep]), end="")
             cprint("g", "    time: %f seconds\n" % (time.time() - t0))
 

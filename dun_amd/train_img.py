@@ -12,6 +12,7 @@ import time
 import numpy as np
 import torch
 
+from dun_amd._epochs import QWarmup, epoch_means
 from dun_amd.probability import depth_categorical_VI
 from dun_amd.stochastic_img_resnets import resnet18, resnet34, resnet50, resnet101
 from dun_amd.training_wrappers import DUN_VI
@@ -39,69 +40,82 @@ def make_image_dun(dataset="CIFAR10", model="resnet50", start_depth=1, end_depth
                   schedule=milestones, regression=False, pred_sig=None)
 
 
+class _ImageRunLog(object):
+    """The five per-epoch curves of an image run and their on-disk form (``stats_array.pkl``: a pickled list of the
+    arrays in the order marginal_loglike, err_train, train_loss, err_dev, dev_loss -- what the reference's evaluation
+    scripts read back)."""
+    FIELDS = ("objective", "train_err", "train_nll", "dev_err", "dev_nll")
+
+    def __init__(self, epochs):
+        self.epochs = epochs
+        for f in self.FIELDS:
+            setattr(self, f, np.zeros(epochs))
+
+    def arrays(self):
+        return [getattr(self, f) for f in self.FIELDS]
+
+    def dump(self, path):
+        with open(path, "wb") as f:
+            pickle.dump(self.arrays(), f)
+
+    def restore(self, path):
+        """Continue from the curves an earlier run of this loop wrote (a run resumed with a longer schedule than the
+        one that wrote the file keeps what it has and gets zeros for the epochs still to come)."""
+        with open(path, "rb") as f:  # a file this loop wrote itself, see dump()
+            stored = pickle.load(f)
+        for name, old in zip(self.FIELDS, stored):
+            fresh = np.zeros(self.epochs)
+            n = min(len(old), self.epochs)
+            fresh[:n] = old[:n]
+            setattr(self, name, fresh)
+
+
+def _resume(net, path, log, best_err1):
+    """-> (first epoch to run, best dev error so far) from a checkpoint of this loop, if there is one at `path`."""
+    if not os.path.isfile(path):
+        print("=> no checkpoint found at '{}'".format(path))
+        return 0, best_err1
+    loaded = net.load(path)
+    start_epoch, best_err1 = loaded if isinstance(loaded, tuple) else (loaded, best_err1)
+    print("=> loaded checkpoint '{}' (epoch {})".format(path, start_epoch))
+    stats = os.path.join(os.path.dirname(path), "stats_array.pkl")
+    if os.path.isfile(stats):
+        log.restore(stats)
+    return start_epoch, best_err1
+
+
 def train_loop(net, train_loader, val_loader, Ntrain, epochs=90, resume="", savedir="./", save_all_epochs=False,
                q_nograd_its=0, best_err1=1.0):
     """Returns (marginal_loglike, err_train, train_loss, err_dev, dev_loss, best_err1), one entry per epoch."""
     mkdir(savedir)
     net.N_train = Ntrain
-    start_epoch = 0
-    marginal_loglike, train_loss, dev_loss = np.zeros(epochs), np.zeros(epochs), np.zeros(epochs)
-    err_train, err_dev = np.zeros(epochs), np.zeros(epochs)
-    stats_file = os.path.join(savedir, "stats_array.pkl")
+    log = _ImageRunLog(epochs)
+    first = 0
     if resume:
-        if os.path.isfile(resume):
-            loaded = net.load(resume)
-            start_epoch, best_err1 = loaded if isinstance(loaded, tuple) else (loaded, best_err1)
-            print("=> loaded checkpoint '{}' (epoch {})".format(resume, start_epoch))
-            progress = os.path.join(os.path.dirname(resume), "stats_array.pkl")
-            if os.path.isfile(progress):
-                with open(progress, "rb") as f:  # written by this loop below
-                    loaded_stats = pickle.load(f)
-                # (a run resumed with a longer schedule than the one that wrote the file keeps what it has)
-                marginal_loglike, err_train, train_loss, err_dev, dev_loss = [
-                    np.concatenate([a[:epochs], np.zeros(max(0, epochs - len(a)))]) for a in loaded_stats]
-        else:
-            print("=> no checkpoint found at '{}'".format(resume))
-    if q_nograd_its > 0:
-        net.prob_model.q_logits.requires_grad = False
-    for epoch in range(start_epoch, epochs):
-        if q_nograd_its > 0 and epoch == q_nograd_its:
-            net.prob_model.q_logits.requires_grad = True
-        tic = time.time()
-        nb_samples = 0
-        for x, y in train_loader:
-            marg_loglike_estimate, minus_loglike, err = net.fit(x, y)
-            marginal_loglike[epoch] += marg_loglike_estimate * x.shape[0]
-            err_train[epoch] += err * x.shape[0]
-            train_loss[epoch] += minus_loglike * x.shape[0]
-            nb_samples += len(x)
-        marginal_loglike[epoch] /= nb_samples
-        train_loss[epoch] /= nb_samples
-        err_train[epoch] /= nb_samples
+        first, best_err1 = _resume(net, resume, log, best_err1)
+    warmup = QWarmup(net.prob_model, q_nograd_its)
+
+    for ep in range(first, epochs):
+        warmup.at_epoch(ep)
+        t0 = time.time()
+        log.objective[ep], log.train_nll[ep], log.train_err[ep] = epoch_means(train_loader, net.fit, 3)
         print("\n depth approx posterior", net.prob_model.current_posterior.data.cpu().numpy())
         print("it %d/%d, ELBO/evidence %.4f, pred minus loglike = %f, err = %f" %
-              (epoch, epochs, marginal_loglike[epoch], train_loss[epoch], err_train[epoch]), end="")
-        cprint("r", "   time: %f seconds\n" % (time.time() - tic))
+              (ep, epochs, log.objective[ep], log.train_nll[ep], log.train_err[ep]), end="")
+        cprint("r", "   time: %f seconds\n" % (time.time() - t0))
         net.update_lr()
-        tic = time.time()
-        nb_samples = 0
-        for x, y in val_loader:
-            minus_loglike, err = net.eval(x, y)
-            dev_loss[epoch] += minus_loglike * x.shape[0]
-            err_dev[epoch] += err * x.shape[0]
-            nb_samples += len(x)
-        dev_loss[epoch] /= nb_samples
-        err_dev[epoch] /= nb_samples
-        cprint("g", "     pred minus loglike = %f, err = %f\n" % (dev_loss[epoch], err_dev[epoch]), end="")
-        cprint("g", "    time: %f seconds\n" % (time.time() - tic))
-        filename = "checkpoint.pth.tar"
-        if save_all_epochs:
-            filename = str(epoch) + "_" + filename
-        net.save(os.path.join(savedir, filename), best_err1)
-        if err_dev[epoch] < best_err1:
-            best_err1 = err_dev[epoch]
-            cprint("b", "best top1 dev err: %f" % err_dev[epoch])
-            shutil.copyfile(os.path.join(savedir, filename), os.path.join(savedir, "model_best.pth.tar"))
-        with open(stats_file, "wb") as f:
-            pickle.dump([marginal_loglike, err_train, train_loss, err_dev, dev_loss], f)
-    return marginal_loglike, err_train, train_loss, err_dev, dev_loss, best_err1
+
+        t0 = time.time()
+        log.dev_nll[ep], log.dev_err[ep] = epoch_means(val_loader, net.eval, 2)
+        cprint("g", "     pred minus loglike = %f, err = %f\n" % (log.dev_nll[ep], log.dev_err[ep]), end="")
+        cprint("g", "    time: %f seconds\n" % (time.time() - t0))
+
+        # the checkpoint carries the best error BEFORE this epoch, like the file the reference writes
+        ckpt = os.path.join(savedir, ("%d_" % ep if save_all_epochs else "") + "checkpoint.pth.tar")
+        net.save(ckpt, best_err1)
+        if log.dev_err[ep] < best_err1:
+            best_err1 = log.dev_err[ep]
+            cprint("b", "best top1 dev err: %f" % best_err1)
+            shutil.copyfile(ckpt, os.path.join(savedir, "model_best.pth.tar"))
+        log.dump(os.path.join(savedir, "stats_array.pkl"))
+    return tuple(log.arrays()) + (best_err1,)

@@ -70,14 +70,7 @@ class DUN(BaseNet):
 
     def _backward(self, act_vec, prior_loglikes, out):
         """Backward of loss = -objective / N_train from the fused pass's d loss / d act_vec."""
-        roots, grads = [act_vec], [out.dact.view_as(act_vec)]
-        if isinstance(prior_loglikes, torch.Tensor) and prior_loglikes.requires_grad:
-            w = out.weights.detach()
-            prior_term = (w * prior_loglikes).sum() if prior_loglikes.dim() == 1 and prior_loglikes.shape[0] == out.D \
-                else w.sum() * prior_loglikes.sum()
-            roots.append(-prior_term / self.N_train)
-            grads.append(None)
-        torch.autograd.backward(roots, grads)
+        torch.autograd.backward([act_vec], [out.dact.view_as(act_vec)])
         # the gradients of q_logits / log_std are views into this step's result block (a fresh tensor per eager step,
         # the static one of a captured step): no copy launches
         q_logits = getattr(self.prob_model, "q_logits", None)
@@ -88,6 +81,17 @@ class DUN(BaseNet):
         if self._dist is not None:
             self._reduce_loose_gradients()
             self._dist.wait_gradients()
+        if isinstance(prior_loglikes, torch.Tensor) and prior_loglikes.requires_grad:
+            # Weight-prior term of the objective (src/DUN/stochastic_fc_models.py:31-50 feeds src/probability.py:173):
+            # joint_d = ... + prior_d, so d objective / d prior_d = w_d (q for the ELBO, the exact posterior for the
+            # marginal); the reference's prior is the scalar sum over layers and broadcasts over depths.  It is a
+            # function of the replicated parameters only, hence identical on every rank of a sharded job: its gradient
+            # is accumulated into the flat gradient buffer AFTER the data-term gradients were summed over ranks (the
+            # exchange would otherwise count it world-size times, and would race with this in-place accumulation).
+            w = out.weights.detach()
+            per_depth = prior_loglikes.dim() == 1 and prior_loglikes.shape[0] == out.D
+            prior_term = (w * prior_loglikes).sum() if per_depth else w.sum() * prior_loglikes.sum()
+            torch.autograd.backward([-prior_term / self.N_train])
 
     def _reduce_loose_gradients(self):
         """Sharded job: sum the gradients that do not live in a flat buffer (conv trunks of image DUNs)."""

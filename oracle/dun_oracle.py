@@ -26,6 +26,8 @@ Reference locations each function follows (paths relative to the reference repo)
   fit_vi / fit_mll ...... src/DUN/training_wrappers.py:212-245 / :54-89
   evaluate / predict .... src/DUN/training_wrappers.py:91-115 / :136-158
   elbo_grads_closed_form  hand-derived backward, SURVEY.md section 8 row a11
+  diag_gauss_prior ...... src/probability.py:30-40 (diag_w_Gauss_loglike)
+  w_prior_loglike ....... src/DUN/stochastic_fc_models.py:26-52 (apply_prior / get_w_prior_loglike)
 """
 import math
 
@@ -177,6 +179,32 @@ def joint_loglike(prior_loglikes, act_vec, y, regression, N_train, log_std=None)
 
 
 # --------------------------------------------------------------------------------------------------
+# weight priors
+# --------------------------------------------------------------------------------------------------
+def diag_gauss_prior(mu=0.0, sig2=1.0, multiplier=1.0):
+    """log N(w; mu, scale) summed over a tensor.  NOTE: the reference hands its ``sig2`` argument to
+    torch.distributions.Normal as the SCALE (standard deviation), not the variance; restated as it behaves."""
+    def f(w):
+        lp = -((w - mu) ** 2) / (2 * sig2 ** 2) - math.log(sig2) - math.log(math.sqrt(2 * math.pi))
+        return lp.sum() * multiplier
+    return f
+
+
+def w_prior_loglike(p, prior_f, bma=False, k=None):
+    """Scalar the reference's get_w_prior_loglike returns when a weight prior is set: per-layer sums of the prior
+    over Linear weights and biases (input + shared output layer form entry 0, block i entry i+1; BatchNorm
+    parameters carry no prior), optionally turned into cumulative sums (BMA_prior), then summed over depth."""
+    n_layers = p["w"].shape[0]
+    k = n_layers if k is None else k
+    first = prior_f(p["w_in"]) + prior_f(p["b_in"]) + prior_f(p["w_out"]) + prior_f(p["b_out"])
+    per_layer = [first] + [prior_f(p["w"][i]) + prior_f(p["b"][i]) for i in range(k)]
+    vec = torch.stack(per_layer, dim=0)
+    if bma:
+        vec = vec.unsqueeze(0).repeat(k + 1, 1).tril(diagonal=0).sum(dim=1)
+    return vec.sum(dim=0)
+
+
+# --------------------------------------------------------------------------------------------------
 # depth categorical: exact marginal and variational posterior
 # --------------------------------------------------------------------------------------------------
 def marg_loglike(joint, logprior):
@@ -292,8 +320,9 @@ class OracleNet(object):
     """State + fit/eval/predict of a DUN over the FC trunk; mirrors DUN / DUN_VI numerics on CPU."""
 
     def __init__(self, params, prior_probs, N_train, lr=1e-2, momentum=0.5, weight_decay=0.0,
-                 regression=True, vi=True, residual=True, pred_sig=None, train_q=True):
+                 regression=True, vi=True, residual=True, pred_sig=None, train_q=True, w_prior=None, bma=False):
         self.p = params
+        self.w_prior, self.bma = w_prior, bma  # callable on a tensor (e.g. diag_gauss_prior(...)) or None
         dt, dev = params["w_in"].dtype, params["w_in"].device  # (state lives where the parameters live)
         self.prior_probs = torch.as_tensor(prior_probs, dtype=dt, device=dev)
         self.logprior = self.prior_probs.log()
@@ -321,7 +350,7 @@ class OracleNet(object):
     def objective(self, x, y, train=True):
         """(objective, joint[D], act_vec) with autograd enabled on whatever leaves require grad."""
         act_vec = fc_forward(self.p, x, train=train, residual=self.residual)
-        prior = torch.zeros(self.D, dtype=act_vec.dtype, device=act_vec.device)
+        prior = self.prior_loglikes()
         joint = joint_loglike(prior, act_vec, y, self.regression, self.N, self.log_std)
         if self.vi:
             e_ll = (q_probs(self.q_logits) * joint).sum()
@@ -329,6 +358,11 @@ class OracleNet(object):
         else:
             obj = marg_loglike(joint, self.logprior)
         return obj, joint, act_vec
+
+    def prior_loglikes(self):
+        if self.w_prior is None:
+            return torch.zeros(self.D, dtype=self.p["w_in"].dtype, device=self.p["w_in"].device)
+        return w_prior_loglike(self.p, self.w_prior, self.bma)
 
     def fit(self, x, y, return_grads=False):
         leaves = self._leaves()
@@ -372,7 +406,7 @@ class OracleNet(object):
 
     def exact_d_posterior(self, batches, train_bn=False):
         with torch.no_grad():
-            prior = torch.zeros(self.D, dtype=self.p["w_in"].dtype, device=self.p["w_in"].device)
+            prior = self.prior_loglikes()
             cum = 0
             for x, y in batches:
                 act_vec = fc_forward(self.p, x, train=train_bn, residual=self.residual)
@@ -383,7 +417,7 @@ class OracleNet(object):
 
     def exact_elbo(self, batches, train_bn=False):
         with torch.no_grad():
-            prior = torch.zeros(self.D, dtype=self.p["w_in"].dtype, device=self.p["w_in"].device)
+            prior = self.prior_loglikes()
             cum = 0.0
             for x, y in batches:
                 act_vec = fc_forward(self.p, x, train=train_bn, residual=self.residual)

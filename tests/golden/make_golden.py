@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 
 with contextlib.redirect_stdout(io.StringIO()):
     from src.probability import depth_categorical, depth_categorical_VI, homo_Gauss_mloglike  # noqa: E402
+    from src.probability import diag_w_Gauss_loglike  # noqa: E402
     from src.DUN.training_wrappers import DUN, DUN_VI  # noqa: E402
     from src.DUN.stochastic_fc_models import arq_uncert_fc_resnet, arq_uncert_fc_MLP  # noqa: E402
     from src.datasets.additional_gap_loader import load_wiggle  # noqa: E402
@@ -54,7 +55,11 @@ def synthetic_regression(B, din, seed):
 def build(cfg):
     torch.manual_seed(cfg["seed"])
     ctor = arq_uncert_fc_MLP if cfg.get("mlp") else arq_uncert_fc_resnet
-    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"], w_prior=None, BMA_prior=False)
+    w_prior = None
+    if cfg.get("w_prior"):  # weight prior of the reference's regression experiments (src/probability.py:30-40)
+        wp = cfg["w_prior"]
+        w_prior = diag_w_Gauss_loglike(wp["mu"], wp["sig2"], wp["mult"])
+    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"], w_prior=w_prior, BMA_prior=bool(cfg.get("bma")))
     D = cfg["L"] + 1
     prior = cfg.get("prior") or [1.0 / D] * D
     if cfg["vi"]:
@@ -98,6 +103,7 @@ def one_pass(net, cfg, x, y):
     log_marg = pm.get_marg_loglike(joint)
     log_post = pm.get_depth_log_posterior(joint, log_marg)
     out["act_vec"] = npy(act_vec)
+    out["prior_ll"] = npy(prior)
     out["loglike"] = npy(ll)
     out["joint"] = npy(joint)
     out["log_marg"] = npy(log_marg)
@@ -371,7 +377,28 @@ def uci_case():
     print("wrote uci_small")
 
 
+def prior_cases():
+    """Weight-prior path: diag_w_Gauss_loglike plain and with BMA_prior, VI and exact-marginal."""
+    base = dict(seed=0, O=1, vi=True, regression=True, wd=0.0)
+    wp = dict(mu=0.0, sig2=0.3, mult=1.0)
+    x, y = synthetic_regression(160, 6, 9)
+    run_case("prior_gauss", dict(base, din=6, W=48, L=3, N=160, lr=1e-2, momentum=0.5, w_prior=wp, sweep=True), x, y)
+    run_case("prior_bma", dict(base, din=6, W=48, L=3, N=160, lr=1e-2, momentum=0.5, bma=True,
+                               w_prior=dict(mu=0.05, sig2=0.5, mult=0.5), sweep=True), x, y)
+    # (N_train 16 against a batch of 160 keeps the exact posterior off one-hot: with a one-hot posterior the predictive
+    #  variance lands on either side of 0 and torch >= 2 refuses the NaN scale inside the reference's Normal)
+    run_case("prior_mll", dict(base, vi=False, din=6, W=48, L=3, N=16, lr=1e-2, momentum=0.5, w_prior=wp), x, y)
+    g = torch.Generator().manual_seed(10)
+    xc = torch.randn(96, 12, generator=g)
+    yc = torch.randint(0, 5, (96,), generator=g)
+    run_case("prior_cls", dict(base, regression=False, din=12, O=5, W=32, L=2, N=96, lr=0.05, momentum=0.9, bma=True,
+                               w_prior=wp), xc, yc)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "prior":
+        prior_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "image":
         image_case()
         return
@@ -401,6 +428,7 @@ def main():
                             wd=1e-4, sweep=True), xc, yc)
     run_case("cls_fc_mll", dict(base, regression=False, vi=False, din=20, O=10, W=64, L=4, N=256, lr=0.05,
                                 momentum=0.9), xc, yc)
+    prior_cases()
     edge_cases()
     head_case()
     image_case()

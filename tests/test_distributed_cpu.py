@@ -59,11 +59,34 @@ def _sweeps(net, x, y, n_dataset):
     return out
 
 
+def _record_collectives(log):
+    """Wrap torch.distributed's collectives in this process: every call appends (op, shape, dtype, async, reduce op)
+    to `log` before it is issued.  Two ranks whose logs differ would wait in different collectives -- the one
+    product-side way to get "both ranks sit in all_reduce with every kernel done"."""
+    real = {k: getattr(dist, k) for k in ("all_reduce", "broadcast", "barrier")}
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        log.append(("all_reduce", tuple(t.shape), str(t.dtype), bool(async_op), str(op)))
+        return real["all_reduce"](t, op=op, group=group, async_op=async_op)
+
+    def broadcast(t, src=0, group=None, async_op=False):
+        log.append(("broadcast", tuple(t.shape), str(t.dtype), bool(async_op), int(src)))
+        return real["broadcast"](t, src=src, group=group, async_op=async_op)
+
+    def barrier(*a, **k):
+        log.append(("barrier",))
+        return real["barrier"](*a, **k)
+
+    dist.all_reduce, dist.broadcast, dist.barrier = all_reduce, broadcast, barrier
+
+
 def _worker(rank, world, port, name, sync_bn, steps, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    _record_collectives(log)
     try:
         from dun_amd.distributed import shard
         c = Case(name)
@@ -79,7 +102,7 @@ def _worker(rank, world, port, name, sync_bn, steps, ret):
         ev = net.eval(xs, ys)
         st = _state(net)
         sweep = _sweeps(net, xs, ys, c.cfg["N"] // world)
-        ret[rank] = (rets, ev, {k: v.numpy() for k, v in st.items()}, sweep)
+        ret[rank] = (rets, ev, {k: v.numpy() for k, v in st.items()}, sweep, log)
     finally:
         dist.destroy_process_group()
 
@@ -109,7 +132,7 @@ def _single(name, steps=2):
     return rets, ev, {k: v.numpy() for k, v in _state(net).items()}, sweep
 
 
-@pytest.mark.parametrize("name", ["c3_reduced", "cls_fc", "mll_small"])
+@pytest.mark.parametrize("name", ["c3_reduced", "cls_fc", "mll_small", "prior_gauss", "prior_mll"])
 def test_two_ranks_match_single_process(name):
     r0, r1 = _run(name, sync_bn=True)
     rets, ev, st, single_sweep = _single(name)
@@ -122,6 +145,8 @@ def test_two_ranks_match_single_process(name):
     for a, b, s_ in zip(r0[3], r1[3], sw):
         assert np.allclose(a, b, rtol=1e-6)
         assert np.allclose(a, s_, rtol=2e-5, atol=1e-5), (a, s_)
+    # both ranks issued the same collectives in the same order (op, shape, dtype, sync/async): fit x2, eval, sweeps
+    assert len(r0[4]) > 0 and r0[4] == r1[4], [(i, a, b) for i, (a, b) in enumerate(zip(r0[4], r1[4])) if a != b][:3]
     for k in st:
         assert np.allclose(r0[2][k], r1[2][k], rtol=0, atol=0), k        # replicas stay bit-identical
         scale = np.abs(st[k]).max()

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import Case, rel_err
+from tests.util import Case, model_prior_kwargs, rel_err
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -76,7 +76,7 @@ def build_cpu_net(c):
     from dun_amd.training_wrappers import DUN, DUN_VI
     cfg = c.cfg
     ctor = arq_uncert_fc_MLP if cfg.get("mlp") else arq_uncert_fc_resnet
-    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"])
+    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"], **model_prior_kwargs(c))
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in c.sub("sd/").items()})
     pm = (depth_categorical_VI if cfg["vi"] else depth_categorical)(c.prior(), cuda=False)
     net = quiet(DUN_VI if cfg["vi"] else DUN, model, pm, cfg["N"], lr=cfg["lr"], momentum=cfg["momentum"],
@@ -88,7 +88,8 @@ def build_cpu_net(c):
     return net
 
 
-@pytest.mark.parametrize("name", ["c2_boston", "mlp_nores", "fixed_sig", "cls_fc", "cls_fc_mll", "mll_small"])
+@pytest.mark.parametrize("name", ["c2_boston", "mlp_nores", "fixed_sig", "cls_fc", "cls_fc_mll", "mll_small",
+                                  "prior_gauss", "prior_bma", "prior_mll", "prior_cls"])
 def test_host_logic_reproduces_goldens(cpu_backend, name):
     c = Case(name)
     cfg = c.cfg
@@ -115,6 +116,41 @@ def test_host_logic_reproduces_goldens(cpu_backend, name):
         assert abs(lm - float(c["sweep/log_marg"])) < 5e-3 * abs(lm)
         if cfg["vi"]:
             assert abs(net.get_exact_ELBO(loader) - float(c["sweep/ELBO"])) < 5e-3 * abs(float(c["sweep/ELBO"]))
+
+
+@pytest.mark.parametrize("name", ["prior_gauss", "prior_bma", "prior_mll", "prior_cls"])
+def test_weight_prior_value_and_gradient(cpu_backend, name):
+    """Row a5: get_w_prior_loglike returns the reference's scalar (plain and BMA_prior), the product's
+    diag_w_Gauss_loglike is the reference's density, and one backward leaves the reference's gradients (data term from
+    the trunk backward + prior term through autograd) in the flat gradient buffer."""
+    from dun_amd.probability import diag_w_Gauss_loglike
+    from tests.util import stacked_grads_from_reference
+    c = Case(name)
+    cfg = c.cfg
+    net = build_cpu_net(c)
+    prior = net.model.get_w_prior_loglike(k=None)
+    assert prior.dim() == 0 and prior.requires_grad
+    assert rel_err(prior.detach(), c["prior_ll"]) < 2e-5
+    wp = cfg["w_prior"]
+    net.model.w_prior = [diag_w_Gauss_loglike(wp["mu"], wp["sig2"], wp["mult"])] * (cfg["L"] + 1)
+    assert rel_err(net.model.get_w_prior_loglike().detach(), c["prior_ll"]) < 2e-5
+    x, y = c.t("x"), c.y()
+    net.model.train()
+    act = net.model.forward(x)
+    prior = net.model.get_w_prior_loglike(k=None)
+    out = net.prob_model.fused_objective(prior, act, y, net.f_neg_loglike, cfg["N"])
+    assert rel_err(out.joint, c["joint"]) < 2e-5
+    assert rel_err(out.objective, c["ELBO"] if cfg["vi"] else c["log_marg"]) < 2e-5
+    net._backward(act, prior, out)
+    for k, v in stacked_grads_from_reference(c).items():
+        assert rel_err(net.model.stacked_grad[k], v) < 5e-4, k
+    # the prior term is not negligible in these cases: without it the weight gradient would be off by far more
+    net2 = build_cpu_net(c)
+    net2.model.train()
+    act2 = net2.model.forward(x)
+    out2 = net2.prob_model.fused_objective(prior.detach(), act2, y, net2.f_neg_loglike, cfg["N"])
+    net2._backward(act2, prior.detach(), out2)
+    assert rel_err(net2.model.stacked_grad["w"], stacked_grads_from_reference(c)["w"]) > 1e-2
 
 
 def test_q_warmup_and_scheduler(cpu_backend):

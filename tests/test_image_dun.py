@@ -108,28 +108,57 @@ def test_image_dun_gpu(name):
     assert rel_err(quiet(net2.fast_predict, x).cpu(), c["fast_pred"]) < 0.1
 
 
-@pytest.mark.gpu
-def test_image_epoch_loop_trains_checkpoints_and_resumes(tmp_path):
+def _epoch_loop_case(tmp_path, cuda):
     """train_img.train_loop (reference: experiments/image/train_DUN.py:145-248) on a tiny synthetic MNIST-shaped set."""
+    import pickle
     from dun_amd.train_img import make_image_dun, train_loop
     torch.manual_seed(0)
     net = quiet(make_image_dun, dataset="MNIST", model="resnet18", start_depth=1, end_depth=5, lr=0.05,
-                milestones=[2], cuda=True)
+                milestones=[2], cuda=cuda)
     torch.backends.cudnn.benchmark = False
     g = torch.Generator().manual_seed(1)
     x = torch.randn(96, 1, 28, 28, generator=g)
     y = (x.mean(dim=(1, 2, 3)) > 0).long() + 2 * (x[:, 0, :14].mean(dim=(1, 2)) > 0).long()   # learnable 4-class labels
     batches = [(x[i:i + 32], y[i:i + 32]) for i in range(0, 96, 32)]
+    q0 = net.prob_model.q_logits.data.clone()
     out = quiet(train_loop, net, batches, batches[:1], 96, epochs=3, savedir=str(tmp_path), q_nograd_its=1)
     elbo, err_tr, nll_tr, err_dev, nll_dev, best = out
     assert np.all(np.isfinite(elbo)) and np.all(np.isfinite(nll_tr)) and np.all(np.isfinite(nll_dev))
     assert elbo[-1] > elbo[0] and nll_tr[-1] < nll_tr[0]
     assert net.epoch == 3 and abs(net.optimizer.param_groups[0]["lr"] - 0.005) < 1e-12   # milestone at epoch 2
-    assert os.path.exists(os.path.join(str(tmp_path), "checkpoint.pth.tar"))
-    assert os.path.exists(os.path.join(str(tmp_path), "stats_array.pkl"))
+    assert net.prob_model.q_logits.requires_grad and not torch.equal(net.prob_model.q_logits.data.cpu(), q0.cpu())
+    assert best == min(1.0, err_dev.min())
+    for f in ("checkpoint.pth.tar", "stats_array.pkl", "model_best.pth.tar"):
+        assert os.path.exists(os.path.join(str(tmp_path), f)), f
+    with open(os.path.join(str(tmp_path), "stats_array.pkl"), "rb") as f:   # written by the loop just above
+        stored = pickle.load(f)
+    # on-disk order of the reference: marginal_loglike, err_train, train_loss, err_dev, dev_loss
+    assert len(stored) == 5 and all(np.array_equal(a, b) for a, b in zip(stored, out[:5]))
     # resume: two more epochs continue the arrays from the checkpointed epoch
     net2 = quiet(make_image_dun, dataset="MNIST", model="resnet18", start_depth=1, end_depth=5, lr=0.05,
-                 milestones=[2], cuda=True)
+                 milestones=[2], cuda=cuda)
     out2 = quiet(train_loop, net2, batches, batches[:1], 96, epochs=5, savedir=str(tmp_path),
                  resume=os.path.join(str(tmp_path), "checkpoint.pth.tar"))
     assert net2.epoch == 5 and np.allclose(out2[0][:3], elbo) and np.all(out2[0][3:] != 0)
+    # every epoch kept, and a resume path that does not exist starts from scratch
+    net3 = quiet(make_image_dun, dataset="MNIST", model="resnet18", start_depth=1, end_depth=5, lr=0.05, cuda=cuda)
+    sub = os.path.join(str(tmp_path), "all")
+    out3 = quiet(train_loop, net3, batches[:1], batches[:1], 32, epochs=2, savedir=sub, save_all_epochs=True,
+                 resume=os.path.join(sub, "nothing_here.pth.tar"))
+    assert os.path.exists(os.path.join(sub, "0_checkpoint.pth.tar")) and os.path.exists(os.path.join(sub, "1_checkpoint.pth.tar"))
+    assert net3.epoch == 2 and np.all(out3[0] != 0)
+
+
+def test_image_epoch_loop_cpu(tmp_path):
+    from dun_amd import kernels
+    from tests.cpu_backend import CpuBackend
+    kernels.set_backend(CpuBackend())
+    try:
+        _epoch_loop_case(tmp_path, cuda=False)
+    finally:
+        kernels.set_backend(None)
+
+
+@pytest.mark.gpu
+def test_image_epoch_loop_trains_checkpoints_and_resumes(tmp_path):
+    _epoch_loop_case(tmp_path, cuda=True)

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import dun_oracle as O
-from tests.util import Case, FC_CASES, rel_err, stacked_grads_from_reference
+from tests.util import Case, FC_CASES, PRIOR_CASES, rel_err, stacked_grads_from_reference
 
 TOL = 2e-5  # same ATen CPU ops on both sides; thread-count dependent summation order leaves ~5e-6
 
@@ -26,7 +26,7 @@ def _noise_bounded(got32, ref32, truth64, slack=4.0, floor=2e-6):
     return rel_err(got32, truth64) <= slack * rel_err(ref32, truth64) + floor
 
 
-@pytest.mark.parametrize("name", FC_CASES)
+@pytest.mark.parametrize("name", FC_CASES + PRIOR_CASES)
 def test_forward_and_probability_chain(name):
     c = Case(name)
     cfg = c.cfg
@@ -37,7 +37,10 @@ def test_forward_and_probability_chain(name):
     assert rel_err(act, c["act_vec"]) < TOL
     ll = O.loglike_per_act(act, y, cfg["regression"], net.log_std)
     assert rel_err(ll, c["loglike"]) < TOL
-    joint = O.joint_loglike(torch.zeros(c.D), act, y, cfg["regression"], cfg["N"], net.log_std)
+    prior = net.prior_loglikes()
+    if c.has("prior_ll"):  # zeros [D] without a weight prior, a scalar (summed over layers) with one
+        assert prior.shape == c["prior_ll"].shape and rel_err(prior, c["prior_ll"]) < TOL
+    joint = O.joint_loglike(prior, act, y, cfg["regression"], cfg["N"], net.log_std)
     assert rel_err(joint, c["joint"]) < TOL
     lm = O.marg_loglike(joint, net.logprior)
     assert rel_err(lm, c["log_marg"]) < TOL
@@ -45,7 +48,7 @@ def test_forward_and_probability_chain(name):
     if cfg["vi"]:
         assert rel_err(O.q_probs(net.q_logits), c["q"]) < TOL
         assert abs(float(O.kl_q_prior(net.q_logits, net.logprior)) - float(c["KL"])) < 1e-6
-        e = O.elbo(torch.zeros(c.D), act, y, cfg["regression"], cfg["N"], net.q_logits, net.logprior, net.log_std)
+        e = O.elbo(prior, act, y, cfg["regression"], cfg["N"], net.q_logits, net.logprior, net.log_std)
         assert rel_err(e, c["ELBO"]) < TOL
     # BN running statistics after one train-mode forward
     after = c.sub("sd_after_fwd/")
@@ -55,7 +58,7 @@ def test_forward_and_probability_chain(name):
         assert int(p["num_batches_tracked"][i]) == int(after["stochstic_layers.%d.block.2.num_batches_tracked" % i])
 
 
-@pytest.mark.parametrize("name", FC_CASES)
+@pytest.mark.parametrize("name", FC_CASES + PRIOR_CASES)
 def test_gradients_and_closed_form(name):
     c = Case(name)
     cfg = c.cfg
@@ -76,7 +79,7 @@ def test_gradients_and_closed_form(name):
     w = O.q_probs(net0.q_logits) if cfg["vi"] else O.depth_log_posterior(joint, net0.logprior).exp()
     cf = O.elbo_grads_closed_form(act, y, cfg["regression"], cfg["N"], w, log_std=net0.log_std, vi=cfg["vi"],
                                   q_logits=net0.q_logits if cfg["vi"] else None, logprior=net0.logprior,
-                                  prior_loglikes=torch.zeros(c.D))
+                                  prior_loglikes=net0.prior_loglikes())
     assert rel_err(cf["dact"], c["g/act_vec"]) < 2e-5
     if cfg["vi"]:
         assert rel_err(cf["dq_logits"], c["g/q_logits"]) < 2e-4
@@ -84,7 +87,7 @@ def test_gradients_and_closed_form(name):
         assert rel_err(cf["dlog_std"], c["g/log_std"]) < 2e-5
 
 
-@pytest.mark.parametrize("name", FC_CASES)
+@pytest.mark.parametrize("name", FC_CASES + PRIOR_CASES)
 def test_fit_trajectory_and_inference(name):
     c = Case(name)
     cfg = c.cfg

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from oracle import dun_oracle as O
-from tests.util import Case, FC_CASES, oracle_grads_with_masks, rel_err, stacked_grads_from_reference
+from tests.util import (Case, FC_CASES, PRIOR_CASES, model_prior_kwargs, oracle_grads_with_masks, rel_err,
+                        stacked_grads_from_reference)
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +28,7 @@ def build_net(c):
     from dun_amd.training_wrappers import DUN, DUN_VI
     cfg = c.cfg
     ctor = arq_uncert_fc_MLP if cfg.get("mlp") else arq_uncert_fc_resnet
-    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"], w_prior=None, BMA_prior=False)
+    model = ctor(cfg["din"], cfg["O"], cfg["W"], cfg["L"], **model_prior_kwargs(c))
     sd = {k: torch.from_numpy(np.array(v)) for k, v in c.sub("sd/").items()}
     model.load_state_dict(sd)
     if cfg["vi"]:
@@ -56,7 +57,7 @@ def oracle64(c):
     return net, x, y
 
 
-@pytest.mark.parametrize("name", FC_CASES)
+@pytest.mark.parametrize("name", FC_CASES + PRIOR_CASES)
 def test_forward_and_objective(name):
     c = Case(name)
     cfg = c.cfg
@@ -97,7 +98,7 @@ def test_forward_and_objective(name):
     assert rel_err(jl.detach().cpu(), c["joint"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", FC_CASES)
+@pytest.mark.parametrize("name", FC_CASES + PRIOR_CASES)
 def test_gradients(name):
     c = Case(name)
     cfg = c.cfg
@@ -151,7 +152,7 @@ def test_gradients(name):
         assert rel_err(net2.f_neg_loglike.log_std.grad.cpu(), net.f_neg_loglike.log_std.grad.cpu()) < 1e-4
 
 
-@pytest.mark.parametrize("name", FC_CASES)
+@pytest.mark.parametrize("name", FC_CASES + PRIOR_CASES)
 def test_fit_eval_predict(name):
     c = Case(name)
     cfg = c.cfg

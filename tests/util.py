@@ -11,6 +11,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 FC_CASES = ["c1_wiggle", "c2_boston", "c2_protein", "c3_reduced", "mll_small", "mlp_nores", "fixed_sig",
             "cls_fc", "cls_fc_mll"]
+# weight-prior path: the reference's diag_w_Gauss_loglike, plain / BMA_prior, VI / exact marginal
+PRIOR_CASES = ["prior_gauss", "prior_bma", "prior_mll", "prior_cls"]
 
 
 class Case(object):
@@ -42,17 +44,45 @@ class Case(object):
         y = self.t("y")
         return y if self.cfg["regression"] else y.long()
 
+    def w_prior_fn(self):
+        """The case's weight prior as the oracle's callable (None for the w_prior=None cases)."""
+        wp = self.cfg.get("w_prior")
+        return None if not wp else O.diag_gauss_prior(wp["mu"], wp["sig2"], wp["mult"])
+
     def oracle_net(self, dtype=torch.float32):
         cfg = self.cfg
         p = O.params_from_reference_state_dict(self.sub("sd/"), cfg["L"], dtype=dtype)
         net = O.OracleNet(p, self.prior(), cfg["N"], lr=cfg["lr"], momentum=cfg["momentum"],
                           weight_decay=cfg["wd"], regression=cfg["regression"], vi=cfg["vi"],
-                          residual=not cfg.get("mlp", False), pred_sig=cfg.get("pred_sig"))
+                          residual=not cfg.get("mlp", False), pred_sig=cfg.get("pred_sig"),
+                          w_prior=self.w_prior_fn(), bma=bool(cfg.get("bma")))
         if cfg["vi"]:
             net.q_logits = self.t("q_logits0").to(dtype)
         if cfg["regression"]:
             net.log_std = self.t("log_std0").to(dtype)
         return net
+
+
+class TestGaussPrior(object):
+    """A weight prior as a caller would hand it to the model constructors: any callable tensor -> scalar.  Defined
+    here, on purpose, instead of importing the product's diag_w_Gauss_loglike: the wrappers must work with any such
+    callable.  Same density as the reference's diag_w_Gauss_loglike (its sigma^2 argument is the Normal's scale)."""
+    __test__ = False
+
+    def __init__(self, mu, scale, mult):
+        self.mu, self.scale, self.mult = mu, scale, mult
+
+    def __call__(self, w):
+        import math
+        lp = -((w - self.mu) ** 2) / (2 * self.scale ** 2) - math.log(self.scale) - 0.5 * math.log(2 * math.pi)
+        return lp.sum() * self.mult
+
+
+def model_prior_kwargs(case):
+    """Constructor kwargs (w_prior, BMA_prior) of a golden case."""
+    wp = case.cfg.get("w_prior")
+    return dict(w_prior=None if not wp else TestGaussPrior(wp["mu"], wp["sig2"], wp["mult"]),
+                BMA_prior=bool(case.cfg.get("bma")))
 
 
 def stacked_grads_from_reference(case, prefix="g/"):
@@ -107,7 +137,8 @@ def oracle_grads_with_masks(case, masks, dtype=torch.float64):
         acts.append(F.linear(h, p["w_out"], p["b_out"]))
     act_vec = torch.stack(acts)
     D = cfg["L"] + 1
-    joint = O.joint_loglike(torch.zeros(D, dtype=dtype), act_vec, y, cfg["regression"], cfg["N"], net.log_std)
+    prior = net.prior_loglikes()  # differentiable w.r.t. the leaves: net.p holds them
+    joint = O.joint_loglike(prior, act_vec, y, cfg["regression"], cfg["N"], net.log_std)
     if cfg["vi"]:
         obj = (O.q_probs(net.q_logits) * joint).sum() - O.kl_q_prior(net.q_logits, net.logprior)
     else:
