@@ -30,14 +30,21 @@ if ROOT not in sys.path:
 
 # torch is imported by the ranks only (import_torch(), called from run_rank): the parent of a self-launched N-rank job
 # starts the ranks as child processes and must never initialise the GPU itself
-torch = None
-
-
 def import_torch():
     global torch
     import torch as _torch
     torch = _torch
     return _torch
+
+
+class _TorchOnFirstUse(object):
+    """Stands in for the module until something needs it (helpers of this file imported by tests / scripts)."""
+
+    def __getattr__(self, name):
+        return getattr(import_torch(), name)
+
+
+torch = _TorchOnFirstUse()
 
 # MI355X peaks (MI355X_MICROARCH.md): HBM3E 8 TB/s; dense fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s
 HBM_PEAK_GBS = 8000.0

@@ -202,6 +202,25 @@ def test_train_fc_loop_plumbing(cpu_backend, tmp_path):
     assert net2.epoch >= 1
 
 
+def test_train_fc_loop_with_exact_marginal_wrapper(cpu_backend, tmp_path):
+    """DUN + depth_categorical (no q_logits) runs through train_fc_DUN as in the reference, which only touches q_logits
+    when a warm-up is requested (src/DUN/train_fc.py:51-57)."""
+    from dun_amd.datasets import Datafeed, load_wiggle
+    from dun_amd.probability import depth_categorical
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_resnet
+    from dun_amd.train_fc import train_fc_DUN
+    from dun_amd.training_wrappers import DUN
+    X, Y = load_wiggle()
+    ds = Datafeed(torch.Tensor(X), torch.Tensor(Y))
+    train = torch.utils.data.DataLoader(ds, batch_size=150, shuffle=False)
+    torch.manual_seed(0)
+    net = quiet(DUN, arq_uncert_fc_resnet(1, 1, 16, 2), depth_categorical([1 / 3.0] * 3, cuda=False), 300, lr=1e-2,
+                momentum=0.9, cuda=False, regression=True)
+    assert not hasattr(net.prob_model, "q_logits")
+    out = quiet(train_fc_DUN, net, "t", str(tmp_path), 150, 3, train, train, False, seed=0, track_posterior=True)
+    assert np.all(np.isfinite(out[0])) and out[5].shape == (3, 3) and out[6].shape == (3, 3)
+
+
 # ------------------------------------------------------------------------------------------------------
 # data feeding (SURVEY.md 8(f) rank 2)
 # ------------------------------------------------------------------------------------------------------
