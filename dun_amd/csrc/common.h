@@ -99,6 +99,48 @@ __device__ __forceinline__ T group_max(T v) {
     return v;
 }
 
+// ---- all-lanes wavefront reductions on the DPP path (no LDS crossbar) ----
+// __shfl_xor is a ds_bpermute: six dependent LDS-crossbar round trips per 64-lane reduction.  Here four DPP steps
+// (xor 1, xor 2 inside quads, mirror inside half rows, mirror inside rows) leave every lane of a 16-lane row with the
+// row total, and the four row totals are combined through v_readlane (scalar broadcast).  Every lane must be active.
+// Fixed order: ((r0 + r1) + (r2 + r3)) over rows, butterfly inside a row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+template <typename T>
+__device__ __forceinline__ T wave_allsum(T v) {
+    v += dpp_move<DPP_QUAD_XOR1>(v);
+    v += dpp_move<DPP_QUAD_XOR2>(v);
+    v += dpp_move<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_move<DPP_ROW_MIRROR>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ float wave_allmax(float v) {
+    v = fmaxf(v, dpp_move<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_move<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_move<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_move<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
+}
+
 // sum over a workgroup of NT threads (NT multiple of 64, <= 1024); result valid in thread 0.
 // `red` is caller-provided LDS of at least NT/64 elements; the call contains two barriers.
 template <int NT, typename T>

@@ -18,23 +18,32 @@ constexpr int GAUSS_PER_BLOCK = 4096;  // 256 threads x float4 x 4
 constexpr int ROWS_PER_BLOCK = 256;    // softmax rows per workgroup
 
 // weight of depth d: w[d], or softmax(w)[d] when the caller hands over logits (q = softmax(q_logits)).
-// Workgroup-cooperative: the max is a scalar loop (uniform loads, no transcendental), the D exponentials are
-// spread over the first wavefront (one expf per lane per 64 depths) and summed by a butterfly; `sh` is one
-// LDS float.  Contains a barrier: call from uniform control flow.  fp32 throughout, as F.softmax.
-__device__ __forceinline__ float depth_weight(const float* __restrict__ w, int w_is_logits, int D, int d, float* sh) {
+// Every wavefront works it out for itself -- lanes stride over the D logits, max and sum by DPP reductions -- so there
+// is no LDS slot, no barrier and no serial scalar loop in front of the streaming part of a kernel (the first version
+// walked the D logits in a scalar loop, summed in wave 0 and published through LDS behind a barrier: of the 9.6 us the
+// Gaussian pass took at D = 51, B = 65536 that chain was the longest dependent piece).  fp32 throughout, as F.softmax.
+// Call with all 64 lanes active.
+__device__ __forceinline__ float depth_weight(const float* __restrict__ w, int w_is_logits, int D, int d) {
     if (w == nullptr) return 0.f;
     if (!w_is_logits) return w[d];
+    const int lane = threadIdx.x & 63;
     float mx = -INFINITY;
-    for (int i = 0; i < D; ++i) mx = fmaxf(mx, w[i]);
-    if (threadIdx.x < 64) {
-        float s = 0.f;
-        for (int i = threadIdx.x; i < D; i += 64) s += expf(w[i] - mx);
-        s = wave_sum(s);
-        if (threadIdx.x == 0) *sh = s;
-    }
-    __syncthreads();
-    return expf(w[d] - mx) / *sh;
+    for (int i = lane; i < D; i += 64) mx = fmaxf(mx, w[i]);
+    mx = wave_allmax(mx);
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += expf(w[i] - mx);
+    s = wave_allsum(s);
+    return expf(w[d] - mx) / s;
 }
+
+// Labels as nn.CrossEntropyLoss / nn.NLLLoss(reduction='none') treat them (src/DUN/training_wrappers.py:29-30):
+// ignore_index = -100 contributes 0 loss and 0 gradient; any other label outside [0, C) is an error there (IndexError
+// on CPU, device assert on CUDA).  Kernels cannot raise: such a row contributes NaN to the per-depth sum (so nothing
+// computed from it looks valid) and no gradient, and the metric kernels count it (metrics[2]), which the wrappers turn
+// into the IndexError with the one host copy a step makes anyway.
+constexpr long long IGNORE_INDEX = -100;
+__device__ __forceinline__ bool label_ok(long long y, int C) { return y >= 0 && y < (long long)C; }
+__device__ __forceinline__ float label_fallback_ll(long long y) { return y == IGNORE_INDEX ? 0.f : __builtin_nanf(""); }
 
 template <bool VEC, bool NT = false>
 __global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__ act, const float* __restrict__ y,
@@ -44,26 +53,32 @@ __global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__
                                                        float* __restrict__ ll, double* __restrict__ partials,
                                                        int nparts) {
     __shared__ double red[4];
-    __shared__ float sh_w;
     const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
-    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
-    const float sigma = fmaxf(expf(log_std[0]), 1e-4f);
-    const float inv_var = 1.f / (sigma * sigma);
-    const float c0 = LOG_SQRT_2PI_F + logf(sigma);
-    const float coef = -(wd * inv_batch) * inv_var;
     const float* a_row = act + (size_t)d * B;
     float* g_row = dact ? dact + (size_t)d * B : nullptr;
     float* l_row = ll ? ll + (size_t)d * B : nullptr;
-    float acc = 0.f;
     const int base = part * GAUSS_PER_BLOCK;
+    float acc = 0.f;
+    if (VEC) {
+        // the streaming loads go out first (branch-free, clamped: B % 4 == 0 and B >= 4 on this path); the depth weight
+        // and sigma (a handful of uniform loads, two DPP reductions, three transcendentals) are worked out under them
+        f32x4 a[4], t[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = base + (it * 256 + tid) * 4;
-        if (VEC) {
+        for (int it = 0; it < 4; ++it) {
+            const int idx = min(base + (it * 256 + tid) * 4, B - 4);
+            a[it] = ld4_stream<NT>(a_row + idx);
+            t[it] = *reinterpret_cast<const f32x4*>(y + idx);
+        }
+        const float wd = depth_weight(w, w_is_logits, D, d);
+        const float sigma = fmaxf(expf(log_std[0]), 1e-4f);
+        const float inv_var = 1.f / (sigma * sigma);
+        const float c0 = LOG_SQRT_2PI_F + logf(sigma);
+        const float coef = -(wd * inv_batch) * inv_var;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = base + (it * 256 + tid) * 4;
             if (idx < B) {
-                const f32x4 a = ld4_stream<NT>(a_row + idx);
-                const f32x4 t = *reinterpret_cast<const f32x4*>(y + idx);
-                f32x4 r = t - a;
+                const f32x4 r = t[it] - a[it];
                 acc += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
                 if (g_row) st4_stream<NT>(g_row + idx, coef * r);
                 if (l_row) {
@@ -73,10 +88,18 @@ __global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__
                     *reinterpret_cast<f32x4*>(l_row + idx) = o;
                 }
             }
-        } else {
+        }
+    } else {
+        const float wd = depth_weight(w, w_is_logits, D, d);
+        const float sigma = fmaxf(expf(log_std[0]), 1e-4f);
+        const float inv_var = 1.f / (sigma * sigma);
+        const float c0 = LOG_SQRT_2PI_F + logf(sigma);
+        const float coef = -(wd * inv_batch) * inv_var;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int i = idx + e;
+                const int i = base + (it * 256 + tid) * 4 + e;
                 if (i < B) {
                     const float r = y[i] - a_row[i];
                     acc += r * r;
@@ -86,8 +109,11 @@ __global__ __launch_bounds__(256) void ll_gauss_kernel(const float* __restrict__
             }
         }
     }
-    const double tot = block_sum<256, double>((double)acc, red);
-    if (tid == 0) partials[(size_t)d * nparts + part] = tot;
+    // per-thread fp32 (<= 16 squares) -> fp64 from the wavefront on; DPP reduction, one barrier, fixed order
+    const double ws = wave_allsum((double)acc);
+    if ((tid & 63) == 0) red[tid >> 6] = ws;
+    __syncthreads();
+    if (tid == 0) partials[(size_t)d * nparts + part] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // Large-batch form of the Gaussian pass (16-byte aligned rows): a workgroup owns 4096 batch columns and walks a
@@ -186,8 +212,7 @@ __global__ __launch_bounds__(256) void ll_softmax_kernel(const float* __restrict
     const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     const int gl = tid % G, grp = tid / G;
     constexpr int NGROUPS = 256 / G;
-    __shared__ float sh_w;
-    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
+    const float wd = depth_weight(w, w_is_logits, D, d);
     const float coef = wd * inv_batch;
     const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
     float acc = 0.f;
@@ -208,12 +233,14 @@ __global__ __launch_bounds__(256) void ll_softmax_kernel(const float* __restrict
         for (int k = 0; k < KMAX; ++k) s += (gl + k * G < C) ? expf(v[k] - mx) : 0.f;
         s = group_sum<G>(s);
         const float lse = mx + logf(s);
-        const int yb = (int)y[row];
+        const long long yl = y[row];
+        const bool ok = label_ok(yl, C);
+        const int yb = ok ? (int)yl : -1;
         float ay = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) ay += (gl + k * G == yb) ? v[k] : 0.f;
         ay = group_sum<G>(ay);
-        const float row_ll = ay - lse;
+        const float row_ll = ok ? ay - lse : label_fallback_ll(yl);
         if (gl == 0) {
             acc += row_ll;
             if (ll) ll[(size_t)d * B + row] = row_ll;
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(256) void ll_softmax_kernel(const float* __restrict
                 const int j = gl + k * G;
                 if (j < C) {
                     const float pr = expf(v[k] - lse);
-                    g[j] = -coef * ((j == yb ? 1.f : 0.f) - pr);
+                    g[j] = ok ? -coef * ((j == yb ? 1.f : 0.f) - pr) : 0.f;
                 }
             }
         }
@@ -248,7 +275,6 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
                                                                    double* __restrict__ partials, int nparts) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ double red[4];
-    __shared__ float sh_w;
     const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     const int r0 = part * ROWS_PER_BLOCK;
     const int nrows = min(ROWS_PER_BLOCK, B - r0);
@@ -257,13 +283,13 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
     const float* src = act + off;
     // every global load of the workgroup is issued before anything waits: the label, then the thread's share of the
     // tile into registers (a run-time trip count made this a load / wait / LDS-store round trip per 4 KiB; branch-free,
-    // clamped addresses), and the depth weight (scalar loads, a wave reduction and a barrier) is worked out underneath
+    // clamped addresses), and the depth weight (a few loads and two DPP reductions per wavefront) is worked out underneath
     const int64_t yv = y[r0 + min(tid, nrows - 1)];
     constexpr int NV = (ROWS_PER_BLOCK * CMAX / 4 + 255) / 256;
     f32x4 stage[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) stage[j] = ld4_stream<NT>(src + min((j * 256 + tid) * 4, nfl - 4));
-    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
+    const float wd = depth_weight(w, w_is_logits, D, d);
     const float coef = wd * inv_batch;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -281,7 +307,8 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
             v[k] = k < C ? a[k] : -INFINITY;
             mx = fmaxf(mx, v[k]);
         }
-        const int yb = min(max((int)yv, 0), C - 1);  // (a label outside [0,C) is clamped, not chased out of the tile)
+        const bool ok = label_ok(yv, C);  // -100 (ignored) and out-of-range labels: no gradient, see label_ok
+        const int yb = ok ? (int)yv : 0;
         const float ay = a[yb];  // the target's logit straight from the staged row (no select per class)
         float s = 0.f;
 #pragma unroll
@@ -290,13 +317,13 @@ __global__ __launch_bounds__(256) void ll_softmax_rowthread_kernel(const float* 
             s += v[k];
         }
         const float lse = mx + logf(s);
-        const float row_ll = ay - lse;
+        const float row_ll = ok ? ay - lse : label_fallback_ll(yv);
         acc = row_ll;
         if (ll) ll[(size_t)d * B + r0 + tid] = row_ll;
         if (dact) {
             // -coef (onehot - softmax) = (coef / s) exp(.) everywhere, minus coef at the target class
-            const float sc = coef / s;
-            const float gy = sc * expf(ay - mx) - coef;
+            const float sc = ok ? coef / s : 0.f;
+            const float gy = sc * expf(ay - mx) - (ok ? coef : 0.f);
 #pragma unroll
             for (int k = 0; k < CMAX; ++k)
                 if (k < C) a[k] = sc * v[k];
@@ -328,7 +355,6 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
                                                                   int tile_rows) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ double red[4];
-    __shared__ float sh_w;
     __shared__ int ytile[ROWS_PER_BLOCK];
     const int d = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     const int gl = tid % G, grp = tid / G;
@@ -341,7 +367,9 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
     // (branch-free, clamped addresses; pass sizes are multiples of 4 floats: r0 % 4 == 0 and B*C % 4 == 0); the depth
     // weight is worked out underneath them.  The logits of pass p+1 are fetched into the same registers while pass p
     // is reduced out of LDS.
-    const int yv = (int)y[row_begin + min(tid, row_end - row_begin - 1)];
+    // label code kept in LDS: the class, -100 (ignored) or -1 (any other label outside [0, C): see label_ok)
+    const long long yl = y[row_begin + min(tid, row_end - row_begin - 1)];
+    const int yv = label_ok(yl, C) ? (int)yl : (yl == IGNORE_INDEX ? (int)IGNORE_INDEX : -1);
     f32x4 stage[NV];
     {
         const int nfl0 = min(tile_rows, row_end - row_begin) * C;
@@ -350,7 +378,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
         for (int j = 0; j < NV; ++j) stage[j] = ld4_stream<NT>(src0 + min((j * 256 + tid) * 4, nfl0 - 4));
     }
     ytile[tid] = yv;
-    const float wd = depth_weight(w, w_is_logits, D, d, &sh_w);
+    const float wd = depth_weight(w, w_is_logits, D, d);
     const float coef = wd * inv_batch;
     float acc = 0.f;
     for (int r0 = row_begin; r0 < row_end; r0 += tile_rows) {
@@ -381,6 +409,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
             }
             mx = group_max<G>(mx);
             const int yb = ytile[r0 - row_begin + row];
+            const bool ok = yb >= 0;
             float s = 0.f, ay = 0.f;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
@@ -390,7 +419,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
             }
             s = group_sum<G>(s);
             ay = group_sum<G>(ay);
-            const float row_ll = ay - (mx + logf(s));
+            const float row_ll = ok ? ay - (mx + logf(s)) : label_fallback_ll(yb);
             if (gl == 0) {
                 acc += row_ll;
                 if (ll) ll[(size_t)d * B + r0 + row] = row_ll;
@@ -400,7 +429,7 @@ __global__ __launch_bounds__(256) void ll_softmax_rowgroup_kernel(const float* _
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k) {
                     const int j = gl + k * G;
-                    if (j < C) a[j] = -coef * ((j == yb ? 1.f : 0.f) - v[k] * inv_s);
+                    if (j < C) a[j] = ok ? -coef * ((j == yb ? 1.f : 0.f) - v[k] * inv_s) : 0.f;
                 }
             }
         }
@@ -430,14 +459,14 @@ __global__ __launch_bounds__(64) void reduce_rows_f64_kernel(const double* __res
 }
 
 // One wavefront turns the per-depth sums into everything the objective and its backward need (fp64 inside).
-__global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __restrict__ sums, int gaussian,
-                                                            const float* __restrict__ q_logits,
-                                                            const float* __restrict__ logprior,
-                                                            const float* __restrict__ prior_ll,
-                                                            const float* __restrict__ log_std, int D, double N,
-                                                            double batch, double beta, double eps, int objective,
-                                                            float* __restrict__ res) {
-    const int lane = threadIdx.x;
+// `sums` may live in global memory or in LDS (generic pointer).
+__device__ __forceinline__ void depth_finalize_body(const double* sums, int gaussian,
+                                                    const float* __restrict__ q_logits,
+                                                    const float* __restrict__ logprior,
+                                                    const float* __restrict__ prior_ll,
+                                                    const float* __restrict__ log_std, int D, double N, double batch,
+                                                    double beta, double eps, int objective, float* __restrict__ res) {
+    const int lane = threadIdx.x & 63;
     float* joint_o = res + DUN_RES_HEADER;
     float* w_o = joint_o + D;
     float* dq_o = w_o + D;
@@ -538,6 +567,42 @@ __global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __rest
     }
 }
 
+__global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __restrict__ sums, int gaussian,
+                                                            const float* __restrict__ q_logits,
+                                                            const float* __restrict__ logprior,
+                                                            const float* __restrict__ prior_ll,
+                                                            const float* __restrict__ log_std, int D, double N,
+                                                            double batch, double beta, double eps, int objective,
+                                                            float* __restrict__ res) {
+    depth_finalize_body(sums, gaussian, q_logits, logprior, prior_ll, log_std, D, N, batch, beta, eps, objective, res);
+}
+
+// reduce_rows_f64_kernel + depth_finalize_kernel in ONE launch (single-device jobs: nothing to exchange between the
+// two): sixteen wavefronts add the per-workgroup partials of the depths (the same lanes-strided + butterfly order as
+// reduce_rows_f64_kernel, so both routes give the same bits), the sums stay in LDS, the first wavefront finalises.
+constexpr int FINALIZE_WAVES = 16;
+__global__ __launch_bounds__(64 * FINALIZE_WAVES) void depth_reduce_finalize_kernel(
+    const double* __restrict__ partials, int nparts, double* __restrict__ sums_out, int gaussian,
+    const float* __restrict__ q_logits, const float* __restrict__ logprior, const float* __restrict__ prior_ll,
+    const float* __restrict__ log_std, int D, double N, double batch, double beta, double eps, int objective,
+    float* __restrict__ res) {
+    extern __shared__ __attribute__((aligned(16))) double sh_sums[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = wave; d < D; d += FINALIZE_WAVES) {
+        double t = 0.0;
+        for (int i = lane; i < nparts; i += 64) t += partials[(size_t)d * nparts + i];
+        t = wave_sum(t);
+        if (lane == 0) {
+            sh_sums[d] = t;
+            if (sums_out) sums_out[d] = t;
+        }
+    }
+    __syncthreads();
+    if (wave == 0)
+        depth_finalize_body(sh_sums, gaussian, q_logits, logprior, prior_ll, log_std, D, N, batch, beta, eps, objective,
+                            res);
+}
+
 // ---- depth-marginal prediction ----
 // value of an fp32 expression, rounded here: the empty asm makes it opaque, so it cannot become one half of an FMA
 __device__ __forceinline__ float rounded(float x) {
@@ -625,7 +690,7 @@ __global__ __launch_bounds__(256) void predict_softmax_kernel(const float* __res
     const int gl = tid % G, grp = tid / G;
     constexpr int NGROUPS = 256 / G;
     const int row_end = min(B, (part + 1) * ROWS_PER_BLOCK);
-    double nll = 0.0, nerr = 0.0;
+    double nll = 0.0, nerr = 0.0, nbad = 0.0;
     for (int row = part * ROWS_PER_BLOCK + grp; row < row_end; row += NGROUPS) {
         float pr[KMAX];
 #pragma unroll
@@ -657,7 +722,9 @@ __global__ __launch_bounds__(256) void predict_softmax_kernel(const float* __res
         for (int k = 0; k < KMAX; ++k)
             if (gl + k * G < C) o[gl + k * G] = pr[k];
         if (partials) {
-            const int yb = (int)y[row];
+            const long long yl = y[row];
+            const bool ok = label_ok(yl, C);
+            const int yb = ok ? (int)yl : -1;
             float py = 0.f, best = -INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
@@ -676,17 +743,21 @@ __global__ __launch_bounds__(256) void predict_softmax_kernel(const float* __res
                 if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
             if (gl == 0) {
-                nll += (double)(-logf(py));
+                // NLLLoss(reduction='none'): 0 for the ignored label; pred.ne(y) counts it as an error all the same
+                nll += ok ? (double)(-logf(py)) : (double)(-label_fallback_ll(yl));
                 nerr += (bi != yb) ? 1.0 : 0.0;
+                nbad += (!ok && yl != IGNORE_INDEX) ? 1.0 : 0.0;
             }
         }
     }
     if (partials) {
         const double t0 = block_sum<256, double>(nll, red);
         const double t1 = block_sum<256, double>(nerr, red);
+        const double t2 = block_sum<256, double>(nbad, red);
         if (tid == 0) {
             partials[part] = t0;
             partials[nparts + part] = t1;
+            partials[2 * nparts + part] = t2;
         }
     }
 }
@@ -710,7 +781,7 @@ __global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* _
     const int part = blockIdx.x, tid = threadIdx.x;
     const int gl = tid % G, grp = tid / G;
     const int row_end = min(B, (part + 1) * rows_wg);  // rows_wg: a multiple of RPP
-    double nll = 0.0, nerr = 0.0;
+    double nll = 0.0, nerr = 0.0, nbad = 0.0;
     for (int r0 = part * rows_wg; r0 < row_end; r0 += RPP) {
         const int nrows = min(RPP, row_end - r0);
         const int nfl = nrows * C;
@@ -725,7 +796,9 @@ __global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* _
 #pragma unroll
             for (int f = 0; f < NF; ++f) pre[f] = ld4_stream<NT>(src + min((f * 256 + tid) * 4, nfl - 4));
         };
-        const int yb = partials ? (int)y[r0 + min(grp, nrows - 1)] : 0;  // on its way under the whole depth loop
+        const long long yl = partials ? y[r0 + min(grp, nrows - 1)] : 0;  // on its way under the whole depth loop
+        const bool ok = label_ok(yl, C);
+        const int yb = ok ? (int)yl : -1;
         fetch(0);
         for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -783,8 +856,9 @@ __global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* _
                     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
                 }
                 if (gl == 0) {
-                    nll += (double)(-logf(py));
+                    nll += ok ? (double)(-logf(py)) : (double)(-label_fallback_ll(yl));
                     nerr += (bi != yb) ? 1.0 : 0.0;
+                    nbad += (!ok && yl != IGNORE_INDEX) ? 1.0 : 0.0;
                 }
             }
         }
@@ -800,9 +874,11 @@ __global__ __launch_bounds__(256) void predict_softmax_lds_kernel(const float* _
     if (partials) {
         const double t0 = block_sum<256, double>(nll, red);
         const double t1 = block_sum<256, double>(nerr, red);
+        const double t2 = block_sum<256, double>(nbad, red);
         if (tid == 0) {
             partials[part] = t0;
             partials[nparts + part] = t1;
+            partials[2 * nparts + part] = t2;
         }
     }
 }
@@ -999,6 +1075,70 @@ extern "C" int dun_depth_finalize(const double* sums, int gaussian, const float*
     return DUN_OK;
 }
 
+constexpr int FINALIZE_FUSED_MAX_D = 4096;  // LDS sums of the one-launch form: 32 KiB
+
+static int finalize_args_ok(const void* in, const float* q_logits, const float* logprior, const float* log_std,
+                            int gaussian, int D, double N_train, double batch, int objective, const float* result,
+                            const char* who) {
+    DUN_REQUIRE(in && logprior && result, "%s: null pointer", who);
+    DUN_REQUIRE(D > 0 && batch > 0 && N_train > 0, "%s: bad sizes", who);
+    DUN_REQUIRE(objective == DUN_OBJ_VI || objective == DUN_OBJ_MLL, "%s: bad objective %d", who, objective);
+    DUN_REQUIRE(objective != DUN_OBJ_VI || q_logits != nullptr, "%s: VI needs q_logits", who);
+    DUN_REQUIRE(!gaussian || log_std != nullptr, "%s: gaussian needs log_std", who);
+    return DUN_OK;
+}
+
+extern "C" int dun_depth_finalize_partials(const double* partials, int nparts, double* sums, int gaussian,
+                                           const float* q_logits, const float* logprior, const float* prior_ll,
+                                           const float* log_std, int D, double N_train, double batch, double beta,
+                                           double eps, int objective, float* result, dun_stream_t stream) {
+    int rc = finalize_args_ok(partials, q_logits, logprior, log_std, gaussian, D, N_train, batch, objective, result,
+                              "dun_depth_finalize_partials");
+    if (rc) return rc;
+    DUN_REQUIRE(nparts > 0, "dun_depth_finalize_partials: nparts=%d", nparts);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (D > FINALIZE_FUSED_MAX_D) {  // (no DUN has thousands of exits; kept correct rather than fast)
+        DUN_REQUIRE(sums != nullptr, "dun_depth_finalize_partials: D=%d > %d needs the sums buffer", D, FINALIZE_FUSED_MAX_D);
+        hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(D), dim3(64), 0, s, partials, nparts, sums);
+        DUN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(64), 0, s, sums, gaussian, q_logits, logprior, prior_ll,
+                           log_std, D, N_train, batch, beta, eps, objective, result);
+    } else {
+        hipLaunchKernelGGL(depth_reduce_finalize_kernel, dim3(1), dim3(64 * FINALIZE_WAVES), (size_t)D * sizeof(double), s,
+                           partials, nparts, sums, gaussian, q_logits, logprior, prior_ll, log_std, D, N_train, batch,
+                           beta, eps, objective, result);
+    }
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+// ---- the whole VI objective of a Gaussian DUN in two launches ------------------------------------------------------
+static int elbo_gauss_impl(const float* act, const float* y, const float* log_std, const float* q_logits,
+                           const float* logprior, const float* prior_ll, int D, int B, double N_train, double beta,
+                           double eps, float* dact, float* result, double* ws, dun_stream_t stream, const char* who) {
+    DUN_REQUIRE(q_logits && logprior && result && ws, "%s: null pointer", who);
+    int rc = dun_ll_gauss(act, y, log_std, q_logits, 1, D, B, (float)(1.0 / (double)B), dact, nullptr, ws, stream);
+    if (rc) return rc;
+    return dun_depth_finalize_partials(ws, dun_ll_num_partials(B, 1), nullptr, 1, q_logits, logprior, prior_ll, log_std,
+                                       D, N_train, (double)B, beta, eps, DUN_OBJ_VI, result, stream);
+}
+
+extern "C" size_t dun_elbo_gauss_workspace_doubles(int D, int B) {
+    if (D <= 0 || B <= 0) return 0;
+    return (size_t)D * (size_t)dun_ll_num_partials(B, 1);
+}
+
+extern "C" int dun_elbo_gauss(const float* act, const float* y, const float* log_std, const float* q_logits,
+                              const float* logprior, const float* prior_ll, int D, int B, double N_train, double beta,
+                              double eps, float* dact, float* result, double* ws, size_t ws_doubles,
+                              dun_stream_t stream) {
+    DUN_REQUIRE(D > 0 && B > 0, "dun_elbo_gauss: empty input D=%d B=%d", D, B);
+    DUN_REQUIRE(D <= FINALIZE_FUSED_MAX_D, "dun_elbo_gauss: D=%d > %d", D, FINALIZE_FUSED_MAX_D);
+    DUN_REQUIRE(ws_doubles >= dun_elbo_gauss_workspace_doubles(D, B), "dun_elbo_gauss: workspace too small");
+    return elbo_gauss_impl(act, y, log_std, q_logits, logprior, prior_ll, D, B, N_train, beta, eps, dact, result, ws,
+                           stream, "dun_elbo_gauss");
+}
+
 extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std,
                                  const float* y, const float* log_std, double* partials, double* metrics,
                                  dun_stream_t stream) {
@@ -1071,7 +1211,7 @@ extern "C" int dun_predict_softmax(const float* act, const float* q, int D, int 
     }
     DUN_LAUNCH_CHECK();
     if (metrics && nparts > 1) {
-        hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);
+        hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(3), dim3(64), 0, s, partials, nparts, metrics);
         DUN_LAUNCH_CHECK();
     }
     return DUN_OK;

@@ -70,11 +70,20 @@ class HipBackend(object):
     name = "hip"
 
     # ---- probability module -------------------------------------------------------------------------
-    def ll_pass(self, act, y, regression, log_std, w, w_is_logits, inv_batch, want_dact=True, want_ll=False):
-        """One streaming pass: per-depth sums (double [D]) [+ dact] [+ ll[D,B]]."""
+    def ll_pass(self, act, y, regression, log_std, w, w_is_logits, inv_batch, want_dact=True, want_ll=False,
+                reduce=True):
+        """One streaming pass: per-depth sums (double [D]) [+ dact] [+ ll[D,B]].  With ``reduce=False`` the first result
+        is the per-workgroup partials (double [D, nparts]) for ``depth_finalize(..., partials=True)``, which adds them
+        up inside the finalisation launch (single-device jobs: nothing to exchange in between)."""
         lib = L.lib()
         D, B = act.shape[0], act.shape[1]
         dev = act.device
+        if y.numel() != B:
+            raise RuntimeError("targets (%d) do not match the batch of act_vec %s" % (y.numel(), tuple(act.shape)))
+        if w is not None and w.numel() != D:
+            raise RuntimeError("depth weights (%d) do not match the number of depths of act_vec (%d)" % (w.numel(), D))
+        if regression and (log_std is None or log_std.numel() != 1):
+            raise RuntimeError("the Gaussian likelihood pass needs a log_std of one element")
         dact = torch.empty_like(act) if want_dact else None
         ll = torch.empty(D, B, device=dev, dtype=torch.float32) if want_ll else None
         s = L.stream_ptr(dev)
@@ -96,6 +105,8 @@ class HipBackend(object):
             L.check(lib.dun_ll_softmax(L.f32(act), L.ptr(y), None if w is None else L.f32(w), int(w_is_logits), D, B,
                                        Cn, float(inv_batch), None if dact is None else L.f32(dact),
                                        None if ll is None else L.f32(ll), L.ptr(partials), s), "dun_ll_softmax")
+        if not reduce:
+            return partials, dact, ll
         if nparts == 1:
             sums = partials.view(D)  # one workgroup per depth: its partial is the sum, no reduction launch
         else:
@@ -104,9 +115,19 @@ class HipBackend(object):
         return sums, dact, ll
 
     def depth_finalize(self, sums, gaussian, q_logits, logprior, prior_ll, log_std, N_train, batch, beta, eps,
-                       objective):
+                       objective, partials=False):
+        """-> result block, or (result block, sums [D]) when `sums` holds unreduced partials [D, nparts]."""
         D = sums.shape[0]
         res = torch.empty(L.res_floats(D), device=sums.device, dtype=torch.float32)
+        if partials:
+            nparts = sums.shape[1]
+            out_sums = torch.empty(D, device=sums.device, dtype=torch.float64)
+            L.check(L.lib().dun_depth_finalize_partials(
+                L.ptr(sums), nparts, L.ptr(out_sums), int(gaussian), None if q_logits is None else L.f32(q_logits),
+                L.f32(logprior), None if prior_ll is None else L.f32(prior_ll),
+                None if log_std is None else L.f32(log_std), D, float(N_train), float(batch), float(beta), float(eps),
+                int(objective), L.f32(res), L.stream_ptr(sums.device)), "dun_depth_finalize_partials")
+            return res, out_sums
         L.check(L.lib().dun_depth_finalize(
             L.ptr(sums), int(gaussian), None if q_logits is None else L.f32(q_logits), L.f32(logprior),
             None if prior_ll is None else L.f32(prior_ll), None if log_std is None else L.f32(log_std), D,
@@ -121,6 +142,12 @@ class HipBackend(object):
         D = act.shape[0]
         s = L.stream_ptr(dev)
         q = q.detach().to(torch.float32).contiguous()
+        if q.numel() != D:
+            # the reference's (q * preds) broadcast raises here too (e.g. predict(x, depth=k) with a full-length posterior)
+            raise RuntimeError("The size of the depth posterior (%d) must match the number of depths of act_vec (%d)"
+                               % (q.numel(), D))
+        if y is not None and y.numel() != (act[0].numel() if regression else act.shape[1]):
+            raise RuntimeError("targets (%d) do not match the batch of act_vec %s" % (y.numel(), tuple(act.shape)))
         metrics = None
         if regression:
             n = act[0].numel()
@@ -140,9 +167,14 @@ class HipBackend(object):
         probs = torch.empty(B, Cn, device=dev, dtype=torch.float32)
         partials = None
         if y is not None:
+            if y.dtype != torch.int64:
+                raise RuntimeError("classification targets must be int64")
             nparts = lib.dun_predict_num_partials(B, max(Cn, 2))
-            partials = torch.empty(2, nparts, device=dev, dtype=torch.float64)
-            metrics = metrics_out if metrics_out is not None else torch.empty(2, device=dev, dtype=torch.float64)
+            partials = torch.empty(3, nparts, device=dev, dtype=torch.float64)
+            # [nll sum, error count, count of labels outside [0,C) other than -100]
+            metrics = metrics_out if metrics_out is not None else torch.empty(3, device=dev, dtype=torch.float64)
+            if metrics.numel() != 3:
+                raise RuntimeError("softmax metrics need a double[3] buffer")
         L.check(lib.dun_predict_softmax(L.f32(act), L.f32(q), D, B, Cn, L.f32(probs), None if y is None else L.ptr(y),
                                         None if partials is None else L.ptr(partials),
                                         None if metrics is None else L.ptr(metrics), s), "dun_predict_softmax")

@@ -115,19 +115,26 @@ def _fused(act_vec, y, f_neg_loglike, N_train, logprior, prior_loglikes, objecti
     prior = _prior_vec(prior_loglikes, D, act)
     ql = None if q_logits is None else q_logits.detach()
     ll = None
+    # single-device jobs have nothing to exchange between the per-workgroup partial sums and the finalisation: the
+    # partials are added up inside the finalisation launch, so the whole objective is two launches
+    local = dist is None
+
+    def finalize(s_, q_, obj):
+        if local:
+            return be.depth_finalize(s_, regression, q_, logprior, prior, ls, N_train, gb, beta, eps, obj, partials=True)
+        dist.all_reduce(s_)
+        return be.depth_finalize(s_, regression, q_, logprior, prior, ls, N_train, gb, beta, eps, obj), s_
+
     if objective == OBJ_VI:
         # q is known before the pass: likelihood, its reduction and dact in ONE sweep over act_vec
         sums, dact, ll = be.ll_pass(act, yy, regression, ls, ql if want_grad else None, True, 1.0 / gb,
-                                    want_dact=want_grad, want_ll=want_ll)
-        if dist is not None:
-            dist.all_reduce(sums)
-        res = be.depth_finalize(sums, regression, ql, logprior, prior, ls, N_train, gb, beta, eps, OBJ_VI)
+                                    want_dact=want_grad, want_ll=want_ll, reduce=not local)
+        res, sums = finalize(sums, ql, OBJ_VI)
     else:
         # the exact posterior needs the complete (all-reduced) per-depth sums first: two sweeps
-        sums, _, ll = be.ll_pass(act, yy, regression, ls, None, False, 1.0 / gb, want_dact=False, want_ll=want_ll)
-        if dist is not None:
-            dist.all_reduce(sums)
-        res = be.depth_finalize(sums, regression, None, logprior, prior, ls, N_train, gb, beta, eps, OBJ_MLL)
+        sums, _, ll = be.ll_pass(act, yy, regression, ls, None, False, 1.0 / gb, want_dact=False, want_ll=want_ll,
+                                 reduce=not local)
+        res, sums = finalize(sums, None, OBJ_MLL)
         dact = None
         if want_grad:
             post = res[RES_HEADER + 3 * D: RES_HEADER + 4 * D]

@@ -108,9 +108,11 @@ class DUN(BaseNet):
         be = kernels.backend()
         act = act_vec.detach()
         post = self.prob_model.current_posterior
-        # [objective,] nll_sum, err_sum in ONE fp64 tensor: the kernel writes its two sums straight into it
-        out = torch.empty(3 if objective is not None else 2, device=act.device, dtype=torch.float64)
-        m = out[-2:]
+        # [objective,] nll_sum, err_sum[, bad_labels] in ONE fp64 tensor: the kernel writes its sums straight into it
+        # (classification carries a third sum: the number of labels outside [0,C) other than the ignored -100)
+        k = 2 if self.regression else 3
+        out = torch.empty(k + (1 if objective is not None else 0), device=act.device, dtype=torch.float64)
+        m = out[-k:]
         if self.regression:
             be.predict(act, post, True, get_std=True, y=y.to(torch.float32).contiguous(),
                        log_std=self.f_neg_loglike.log_std.detach(), metrics_out=m)
@@ -128,8 +130,14 @@ class DUN(BaseNet):
     def _metrics_host(self, m, n):
         """ONE device->host copy for everything fit / eval return."""
         vals = m.tolist()
-        obj = vals[0] if len(vals) == 3 else None
-        nll_sum, err_sum = vals[-2], vals[-1]
+        k = 2 if self.regression else 3
+        obj = vals[0] if len(vals) == k + 1 else None
+        nll_sum, err_sum = vals[-k], vals[-k + 1]
+        if not self.regression and vals[-1] > 0:
+            # nn.CrossEntropyLoss / nn.NLLLoss raise on such labels before anything is computed (IndexError "Target ... is
+            # out of bounds" on CPU); here the count comes home with the step's one host copy, so the step has run (on
+            # the valid rows only: the kernels give such rows no gradient) when this is raised
+            raise IndexError("Target out of bounds: %d label(s) outside [0, C) (and not the ignored -100)" % int(vals[-1]))
         nll = nll_sum / n
         err = (err_sum / n) ** 0.5 if self.regression else err_sum / n
         return obj, nll, err

@@ -57,7 +57,11 @@ int dun_ll_gauss(const float* act, const float* y, const float* log_std, const f
                  int D, int B, float inv_batch, float* dact, float* ll, double* partials, dun_stream_t stream);
 
 /* Softmax cross-entropy pass.  act [D,B,C], y int64 [B].  partials: per-workgroup sums of the row
- * log-likelihood a[y] - logsumexp(a).  dact = -(w_d * inv_batch) * (onehot(y) - softmax(a)).  C <= 1024. */
+ * log-likelihood a[y] - logsumexp(a).  dact = -(w_d * inv_batch) * (onehot(y) - softmax(a)).  C <= 1024.
+ * Labels as nn.CrossEntropyLoss(reduction='none') treats them (src/DUN/training_wrappers.py:29): y == -100
+ * (ignore_index) contributes 0 log-likelihood and a zero gradient row; any other label outside [0,C) -- an error in
+ * the reference -- contributes NaN to its depth's sum and a zero gradient row (never an out-of-bounds access), and
+ * dun_predict_softmax counts such labels in metrics[2] so that a caller can raise without an extra sync. */
 int dun_ll_softmax(const float* act, const int64_t* y, const float* w, int w_is_logits, int D, int B, int C,
                    float inv_batch, float* dact, float* ll, double* partials, dun_stream_t stream);
 
@@ -84,20 +88,41 @@ int dun_depth_finalize(const double* sums, int gaussian, const float* q_logits, 
                        const float* prior_ll, const float* log_std, int D, double N_train, double batch,
                        double beta, double eps, int objective, float* result, dun_stream_t stream);
 
+/* dun_ll_reduce + dun_depth_finalize in ONE launch, for jobs with nothing to exchange between the two (one device):
+ * partials double [D, nparts] as written by dun_ll_gauss / dun_ll_softmax; sums (nullable) receives the per-depth
+ * sums, bit-identical to dun_ll_reduce's.  Same reference lines as dun_depth_finalize. */
+int dun_depth_finalize_partials(const double* partials, int nparts, double* sums, int gaussian,
+                                const float* q_logits, const float* logprior, const float* prior_ll,
+                                const float* log_std, int D, double N_train, double batch, double beta, double eps,
+                                int objective, float* result, dun_stream_t stream);
+
+/* The whole variational objective of a Gaussian-likelihood DUN on one device, two launches: the streaming pass of
+ * dun_ll_gauss (w = q_logits as logits, inv_batch = 1/B) and dun_depth_finalize_partials (batch = B, DUN_OBJ_VI).
+ * Replaces depth_categorical_VI.estimate_ELBO (src/probability.py:246-253 over :162-174 and :54-60) and autograd's
+ * backward through it: dact [D,B] = d(-ELBO/N_train)/d act, result as laid out above.
+ * ws: scratch of at least dun_elbo_gauss_workspace_doubles(D, B) doubles (the per-workgroup partial sums). */
+size_t dun_elbo_gauss_workspace_doubles(int D, int B);
+int dun_elbo_gauss(const float* act, const float* y, const float* log_std, const float* q_logits,
+                   const float* logprior, const float* prior_ll, int D, int B, double N_train, double beta, double eps,
+                   float* dact, float* result, double* ws, size_t ws_doubles, dun_stream_t stream);
+
 /* Depth-marginal prediction, replaces depth_categorical.marginalise_d_predict (src/probability.py:188-208)
  * and, when y != NULL, the train/eval metrics of src/DUN/training_wrappers.py:76-87, 101-113, 231-242.
  * Gaussian: act [D,n] (n = B*O), q [D] probabilities -> mean [n], std [n] (nullable) = sqrt(sum q a^2 - mean^2)
  *   (NaN for a negative variance, as model_var.pow(0.5) in the reference).
  *   metrics (nullable, double [2]; needs y [n] and log_std [1]): sum_b NLL(mean, y, sqrt(sigma^2 + std^2)),
- *   sum_b (mean - y)^2.  Zero it before the call; workgroups accumulate through partials + one reduce. */
+ *   sum_b (mean - y)^2.  Overwritten (no need to zero it); partials: double [2][dun_predict_num_partials(n, 1)]. */
 int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std, const float* y,
                       const float* log_std, double* partials, double* metrics, dun_stream_t stream);
 /* Softmax: act [D,B,C] -> probs [B,C] = sum_d q_d softmax(act[d,b,:]).
- *   metrics (nullable, double [2]; needs y int64 [B]): sum_b -log probs[b,y_b], count(argmax != y). */
+ *   metrics (nullable, double [3]; needs y int64 [B]): sum_b -log probs[b,y_b], count(argmax != y), count of labels
+ *   outside [0,C) other than -100.  y == -100 adds 0 to the first (nn.NLLLoss's ignore_index,
+ *   src/DUN/training_wrappers.py:30) and 1 to the second (pred.ne(y), :87); an out-of-range label adds NaN to the
+ *   first.  partials: double [3][dun_predict_num_partials(B, C)]. */
 int dun_predict_softmax(const float* act, const float* q, int D, int B, int C, float* probs, const int64_t* y,
                         double* partials, double* metrics, dun_stream_t stream);
-/* Size of `partials` for the two predictors: double [2][dun_predict_num_partials(n, C)] (an upper bound of the
- * workgroups a call launches; C = 1 for the Gaussian predictor). */
+/* Columns of `partials` for the two predictors (an upper bound of the workgroups a call launches; C = 1 for the
+ * Gaussian predictor, which has two rows; the softmax predictor has three). */
 int dun_predict_num_partials(int n, int C);
 
 /* ------------------------------------------------------------------------------------------------------

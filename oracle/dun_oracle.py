@@ -156,8 +156,16 @@ def gauss_nll(mu, y, log_std, model_std=None):
     return LOG_SQRT_2PI + torch.log(sig) + (y - mu) ** 2 / (2 * sig ** 2)
 
 
-def ce_rows(logits, y):
-    return torch.logsumexp(logits, dim=1) - logits.gather(1, y.view(-1, 1)).squeeze(1)
+def ce_rows(logits, y, ignore_index=-100):
+    """CrossEntropyLoss(reduction='none'): rows labelled ``ignore_index`` give 0 (and no gradient); any other label
+    outside [0, C) raises, as torch does on CPU."""
+    C = logits.shape[1]
+    keep = y != ignore_index
+    if bool(((y < 0) | (y >= C))[keep].any()):
+        raise IndexError("Target out of bounds")
+    safe = torch.where(keep, y, torch.zeros_like(y))
+    rows = torch.logsumexp(logits, dim=1) - logits.gather(1, safe.view(-1, 1)).squeeze(1)
+    return torch.where(keep, rows, torch.zeros_like(rows))
 
 
 def loglike_per_act(act_vec, y, regression, log_std=None):
@@ -272,8 +280,9 @@ def elbo_grads_closed_form(act_vec, y, regression, N_train, q_or_post, log_std=N
         out["dlog_std"] = -(1.0 / B) * (w * (r ** 2 / sig ** 2 - 1.0)).sum(dim=(0, 1)) * live
     else:
         sm = F.softmax(act_vec, dim=2)
-        oh = F.one_hot(y, act_vec.shape[2]).to(act_vec.dtype).unsqueeze(0)
-        out["dact"] = -(w / B) * (oh - sm)
+        keep = (y != -100)
+        oh = F.one_hot(torch.where(keep, y, torch.zeros_like(y)), act_vec.shape[2]).to(act_vec.dtype).unsqueeze(0)
+        out["dact"] = -(w / B) * (oh - sm) * keep.view(1, B, 1).to(act_vec.dtype)  # ignored rows: no gradient
     if vi and q_logits is not None:
         joint = joint_loglike(prior_loglikes, act_vec, y, regression, N_train, log_std)
         q = q_probs(q_logits)

@@ -9,7 +9,7 @@ lib = L.lib()
 D = 51
 ls = torch.zeros(1, device="cuda"); ql = 0.1 * torch.randn(D, device="cuda")
 print("D=%d" % D)
-for logB in (13, 16, 18, 20, 22, 23):
+for logB in (13, 16, 18, 20, 22, 23):  # 2^16 = the c3_wide configuration
     B = 1 << logB
     act = torch.randn(D, B, device="cuda"); y = torch.randn(B, device="cuda")
     dact = torch.empty_like(act)

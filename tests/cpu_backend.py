@@ -45,7 +45,13 @@ class CpuBackend(object):
     name = "cpu-standin"
 
     # ---- probability module ----
-    def ll_pass(self, act, y, regression, log_std, w, w_is_logits, inv_batch, want_dact=True, want_ll=False):
+    def ll_pass(self, act, y, regression, log_std, w, w_is_logits, inv_batch, want_dact=True, want_ll=False,
+                reduce=True):
+        """(`reduce=False`: the kernels hand back per-workgroup partials [D, nparts]; here one partial per depth)"""
+        sums, dact, ll = self._ll_pass(act, y, regression, log_std, w, w_is_logits, inv_batch, want_dact, want_ll)
+        return (sums if reduce else sums.view(-1, 1)), dact, ll
+
+    def _ll_pass(self, act, y, regression, log_std, w, w_is_logits, inv_batch, want_dact, want_ll):
         D, B = act.shape[0], act.shape[1]
         wt = None
         if w is not None:
@@ -62,17 +68,28 @@ class CpuBackend(object):
             if want_dact:
                 dact = (-(wt.view(D, 1) * inv_batch) * r / sig ** 2).reshape(act.shape)
             return sums, dact, ll
+        # label semantics of the kernels (include/dun_hip.h, dun_ll_softmax): -100 is ignored, any other label outside
+        # [0,C) poisons its depth's sum with NaN; neither gets a gradient
+        C = act.shape[2]
+        ok = (y >= 0) & (y < C)
+        ys = torch.where(ok, y, torch.zeros_like(y))
         lsm = F.log_softmax(act, dim=2)
-        llv = lsm.gather(2, y.view(1, B, 1).expand(D, B, 1)).squeeze(2)
+        llv = lsm.gather(2, ys.view(1, B, 1).expand(D, B, 1)).squeeze(2)
+        fallback = torch.where(y == -100, torch.zeros(B), torch.full((B,), float("nan")))
+        llv = torch.where(ok.view(1, B), llv, fallback.view(1, B).to(llv.dtype))
         sums = llv.double().sum(dim=1)
         dact = None
         if want_dact:
-            oh = F.one_hot(y, act.shape[2]).to(act.dtype).unsqueeze(0)
-            dact = -(wt.view(D, 1, 1) * inv_batch) * (oh - lsm.exp())
+            oh = F.one_hot(ys, C).to(act.dtype).unsqueeze(0)
+            dact = -(wt.view(D, 1, 1) * inv_batch) * (oh - lsm.exp()) * ok.view(1, B, 1).to(act.dtype)
         return sums, dact, (llv if want_ll else None)
 
     def depth_finalize(self, sums, gaussian, q_logits, logprior, prior_ll, log_std, N_train, batch, beta, eps,
-                       objective):
+                       objective, partials=False):
+        if partials:
+            s_ = sums.sum(dim=1)
+            return self.depth_finalize(s_, gaussian, q_logits, logprior, prior_ll, log_std, N_train, batch, beta, eps,
+                                       objective), s_
         D = sums.shape[0]
         res = torch.zeros(H_ + 5 * D)
         lp = logprior.double()
@@ -125,9 +142,14 @@ class CpuBackend(object):
         probs = (qb * F.softmax(act, dim=2)).sum(0)
         metrics = None
         if y is not None:
-            nll = -torch.log(probs.gather(1, y.view(-1, 1))).double().sum()
+            C = act.shape[2]
+            ok = (y >= 0) & (y < C)
+            ys = torch.where(ok, y, torch.zeros_like(y))
+            row = -torch.log(probs.gather(1, ys.view(-1, 1))).squeeze(1).double()
+            bad = ~ok & (y != -100)
+            row = torch.where(ok, row, torch.where(bad, torch.full_like(row, float("nan")), torch.zeros_like(row)))
             err = probs.max(dim=1)[1].ne(y).double().sum()
-            metrics = torch.stack([nll, err])
+            metrics = torch.stack([row.sum(), err, bad.double().sum()])
             if metrics_out is not None:
                 metrics = metrics_out.copy_(metrics)
         return probs, None, metrics

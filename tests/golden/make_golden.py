@@ -377,6 +377,45 @@ def uci_case():
     print("wrote uci_small")
 
 
+def label_cases():
+    """Label semantics of the reference's classification losses (src/DUN/training_wrappers.py:29-30, :85-87):
+    ignore_index rows through CrossEntropyLoss(reduction='none') in the ELBO and through NLLLoss / pred.ne(y) in the
+    metrics; a label outside [0, C) raises."""
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    f = torch.nn.CrossEntropyLoss(reduction="none")
+    f_test = torch.nn.NLLLoss(reduction="none")
+    for C, D, B in ((10, 4, 64), (100, 3, 36), (3, 2, 7)):
+        act = (2.0 * torch.randn(D, B, C, generator=g)).requires_grad_(True)
+        y = torch.randint(0, C, (B,), generator=g)
+        y[torch.randperm(B, generator=g)[:max(2, B // 5)]] = -100
+        pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=False)
+        pm.q_logits.data = 0.5 * torch.randn(D, generator=g)
+        N = 777
+        prior = torch.zeros(D)
+        ELBO = pm.estimate_ELBO(prior, act, y, f, N, Beta=1)
+        joint = depth_categorical.get_w_joint_loglike(prior, act, y, f, N)
+        (-ELBO / N).backward()
+        p = "c%d/" % C
+        out[p + "act"], out[p + "y"], out[p + "q_logits"], out[p + "N"] = npy(act), npy(y), npy(pm.q_logits), np.array(N)
+        out[p + "loglike"] = npy(-f(act.view(D * B, C), y.repeat(D)).view(D, B))
+        out[p + "joint"], out[p + "ELBO"] = npy(joint), npy(ELBO)
+        out[p + "g_act"], out[p + "g_q_logits"] = npy(act.grad), npy(pm.q_logits.grad)
+        probs = depth_categorical.marginalise_d_predict(act.data, pm.get_q_probs(), softmax=True)
+        out[p + "nll"] = npy(f_test(torch.log(probs), y).mean(dim=0))
+        out[p + "err"] = np.array(probs.max(dim=1)[1].ne(y).sum().item() / y.shape[0])
+        for tag, bad in (("hi", C), ("neg", -1)):
+            yb = y.clone()
+            yb[0] = bad
+            try:
+                f(act.detach().view(D * B, C), yb.repeat(D))
+                out[p + "raises_" + tag] = np.array(0)
+            except IndexError:
+                out[p + "raises_" + tag] = np.array(1)
+    np.savez_compressed(os.path.join(HERE, "labels.npz"), **out)
+    print("wrote labels")
+
+
 def prior_cases():
     """Weight-prior path: diag_w_Gauss_loglike plain and with BMA_prior, VI and exact-marginal."""
     base = dict(seed=0, O=1, vi=True, regression=True, wd=0.0)
@@ -398,6 +437,9 @@ def prior_cases():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "prior":
         prior_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "labels":
+        label_cases()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "image":
         image_case()
@@ -429,6 +471,7 @@ def main():
     run_case("cls_fc_mll", dict(base, regression=False, vi=False, din=20, O=10, W=64, L=4, N=256, lr=0.05,
                                 momentum=0.9), xc, yc)
     prior_cases()
+    label_cases()
     edge_cases()
     head_case()
     image_case()

@@ -153,6 +153,32 @@ def test_weight_prior_value_and_gradient(cpu_backend, name):
     assert rel_err(net2.model.stacked_grad["w"], stacked_grads_from_reference(c)["w"]) > 1e-2
 
 
+def check_label_semantics_through_the_wrapper(net_builder):
+    """fit / eval with an ignored (-100) label run and agree with the oracle; any other label outside [0, C) raises
+    IndexError like nn.CrossEntropyLoss does on CPU -- from the step's one host copy."""
+    c = Case("cls_fc")
+    x, y = c.t("x"), c.y().clone()
+    y[3] = y[17] = -100
+    net = net_builder(c)
+    onet = c.oracle_net()
+    for step in range(2):
+        got, want = net.fit(x, y), onet.fit(x, y)
+        assert np.allclose(got, want, rtol=2e-5 if step == 0 else 5e-3), (got, want)
+    onet.current_posterior = onet.current_posterior.detach()
+    assert np.allclose(net.eval(x, y), onet.evaluate(x, y), rtol=5e-3)
+    for bad in (10, -1):
+        yb = c.y().clone()
+        yb[5] = bad
+        with pytest.raises(IndexError):
+            net_builder(c).fit(x, yb)
+        with pytest.raises(IndexError):
+            net.eval(x, yb)
+
+
+def test_label_semantics_through_the_wrapper(cpu_backend):
+    check_label_semantics_through_the_wrapper(build_cpu_net)
+
+
 def test_q_warmup_and_scheduler(cpu_backend):
     """Callers freeze q_logits for the first epochs (src/DUN/train_fc.py:51-57): a frozen q must not move."""
     c = Case("c2_boston")

@@ -209,6 +209,73 @@ def test_elbo_softmax_sizes(be, D, B, C):
     assert m.cpu()[1].item() == float((pr.max(dim=1)[1] != y).sum())
 
 
+@pytest.mark.parametrize("C", [10, 100, 3])
+def test_label_semantics(be, C):
+    """-100 rows: 0 log-likelihood, zero gradient row, 0 NLL but counted as an error (labels.npz, from the reference's
+    CrossEntropyLoss / NLLLoss / pred.ne); labels outside [0,C): NaN sum, zero gradient row, counted in metrics[2].
+    C = 10: thread-per-row kernel, 100: lane groups out of LDS, 3 (B*C % 4 != 0): the unaligned kernels."""
+    e = Case("labels")
+    p = "c%d/" % C
+    act, y, ql, N = e.t(p + "act"), e.t(p + "y").long(), e.t(p + "q_logits"), int(e[p + "N"])
+    D, B = act.shape[0], act.shape[1]
+    res, dact, ll, _ = _run_vi(be, act, y, False, ql, None, N)
+    assert rel_err(ll, e[p + "loglike"]) < 1e-5 and bool((ll[:, y == -100] == 0).all())
+    assert rel_err(res[8:8 + D], e[p + "joint"]) < 1e-5 and rel_err(res[0], e[p + "ELBO"]) < 1e-5
+    assert rel_err(dact, e[p + "g_act"]) < 1e-5 and bool((dact[:, y == -100] == 0).all())
+    assert rel_err(res[8 + 2 * D:8 + 3 * D], e[p + "g_q_logits"]) < 1e-4
+    q = O.q_probs(ql)
+    _, _, m = be.predict(dev(act), dev(q), False, y=dev(y))
+    m = m.cpu()
+    assert abs(m[0].item() / B - float(e[p + "nll"])) < 1e-5 * float(e[p + "nll"])
+    assert m[1].item() / B == float(e[p + "err"]) and m[2].item() == 0
+    for bad in (C, -1, 2 ** 32 + 1):
+        yb = y.clone()
+        yb[1] = bad
+        yb[B - 1] = bad
+        res, dact, ll, sums = _run_vi(be, act, yb, False, ql, None, N)
+        assert bool(torch.isnan(sums).all()) and bool(torch.isnan(res[0]))
+        assert bool((dact[:, 1] == 0).all()) and bool((dact[:, B - 1] == 0).all())
+        keep = torch.ones(B, dtype=torch.bool)
+        keep[1] = keep[B - 1] = False
+        assert rel_err(dact[:, keep], e[p + "g_act"][:, keep.numpy()]) < 1e-5   # the other rows are untouched
+        _, _, m = be.predict(dev(act), dev(q), False, y=dev(yb))
+        assert m.cpu()[2].item() == 2 and bool(torch.isnan(m.cpu()[0]))
+
+
+def test_objective_in_two_launches_matches_three(be):
+    """dun_depth_finalize_partials (reduce + finalise in one launch) and dun_elbo_gauss (pass + that) against the
+    separate dun_ll_gauss / dun_ll_reduce / dun_depth_finalize launches: bit for bit."""
+    from dun_amd import _lib as L
+    lib = L.lib()
+    for D, B in ((51, 65536), (11, 512), (3, 4099), (70, 300), (1, 1)):
+        g = torch.Generator().manual_seed(D + B)
+        act, y = dev(torch.randn(D, B, generator=g)), dev(torch.randn(B, generator=g))
+        ql, ls = dev(0.3 * torch.randn(D, generator=g)), dev(torch.tensor([0.1]))
+        logprior = dev(torch.full((D,), 1.0 / D).log())
+        prior = dev(torch.randn(D, generator=g))
+        N = float(1 << 20)
+        sums, dact, _ = be.ll_pass(act, y, True, ls, ql, True, 1.0 / B)
+        res3 = be.depth_finalize(sums, True, ql, logprior, prior, ls, N, B, 1.0, 1e-35, 0)
+        parts, dact2, _ = be.ll_pass(act, y, True, ls, ql, True, 1.0 / B, reduce=False)
+        res2, sums2 = be.depth_finalize(parts, True, ql, logprior, prior, ls, N, B, 1.0, 1e-35, 0, partials=True)
+        assert torch.equal(res2, res3) and torch.equal(sums2, sums) and torch.equal(dact, dact2)
+        n_ws = lib.dun_elbo_gauss_workspace_doubles(D, B)
+        ws = torch.empty(n_ws, device="cuda", dtype=torch.float64)
+        res1 = torch.full_like(res3, float("nan"))
+        dact1 = torch.full_like(dact, float("nan"))
+        L.check(lib.dun_elbo_gauss(L.f32(act), L.f32(y), L.f32(ls), L.f32(ql), L.f32(logprior), L.f32(prior), D, B, N,
+                                   1.0, 1e-35, L.f32(dact1), L.f32(res1), L.ptr(ws), n_ws, L.stream_ptr(act.device)))
+        assert torch.equal(res1, res3) and torch.equal(dact1, dact)
+        assert lib.dun_elbo_gauss(L.f32(act), L.f32(y), L.f32(ls), L.f32(ql), L.f32(logprior), None, D, B, N, 1.0, 1e-35,
+                                  L.f32(dact1), L.f32(res1), L.ptr(ws), max(n_ws - 1, 0), L.stream_ptr(act.device)) == 1
+    # exact marginal (MLL) through the fused finalisation
+    sums, _, _ = be.ll_pass(act, y, True, ls, None, False, 1.0 / B, want_dact=False)
+    r3 = be.depth_finalize(sums, True, None, logprior, None, ls, N, B, 1.0, 1e-35, 1)
+    parts, _, _ = be.ll_pass(act, y, True, ls, None, False, 1.0 / B, want_dact=False, reduce=False)
+    r2, _ = be.depth_finalize(parts, True, None, logprior, None, ls, N, B, 1.0, 1e-35, 1, partials=True)
+    assert torch.equal(r2, r3)
+
+
 # B >= 2^21 takes the depth-walking kernel: ragged last chunk, and D > 64 (more than one depth group per chunk)
 @pytest.mark.parametrize("D,B", [(51, 65536), (11, 512), (3, 4099), (7, 1), (5, (1 << 21) + 1028), (66, 1 << 21)])
 def test_elbo_gauss_sizes(be, D, B):

@@ -187,6 +187,33 @@ def test_edge_cases_classification(C):
     assert rel_err(O.marginalise_predict(act, O.q_probs(ql), softmax=True), e[p + "probs"]) < TOL
 
 
+@pytest.mark.parametrize("C", [10, 100, 3])
+def test_label_semantics(C):
+    """labels.npz: rows labelled -100 through the reference's CrossEntropyLoss / NLLLoss / pred.ne(y); labels outside
+    [0, C) raise there and here."""
+    e = Case("labels")
+    p = "c%d/" % C
+    act, y, ql, N = e.t(p + "act"), e.t(p + "y").long(), e.t(p + "q_logits"), int(e[p + "N"])
+    D, B = act.shape[0], act.shape[1]
+    assert int((y == -100).sum()) >= 2
+    logprior = torch.full((D,), 1.0 / D).log()
+    assert rel_err(O.loglike_per_act(act, y, False), e[p + "loglike"]) < TOL
+    assert rel_err(O.joint_loglike(torch.zeros(D), act, y, False, N), e[p + "joint"]) < TOL
+    assert rel_err(O.elbo(torch.zeros(D), act, y, False, N, ql, logprior), e[p + "ELBO"]) < TOL
+    cf = O.elbo_grads_closed_form(act, y, False, N, O.q_probs(ql), q_logits=ql, logprior=logprior,
+                                  prior_loglikes=torch.zeros(D))
+    assert rel_err(cf["dact"], e[p + "g_act"]) < 2e-5
+    assert rel_err(cf["dq_logits"], e[p + "g_q_logits"]) < 2e-4
+    nll, err = O._train_metrics(act, y, O.q_probs(ql), False, None)
+    assert abs(nll - float(e[p + "nll"])) < 2e-5 * abs(nll) and err == float(e[p + "err"])
+    assert int(e[p + "raises_hi"]) == 1 and int(e[p + "raises_neg"]) == 1
+    for bad in (C, -1):
+        yb = y.clone()
+        yb[0] = bad
+        with pytest.raises(IndexError):
+            O.loglike_per_act(act, yb, False)
+
+
 def test_wiggle_generator_matches_reference():
     c = Case("c1_wiggle")
     X, Y = O.wiggle_data()

@@ -247,6 +247,21 @@ def test_seed_matched_construction_and_checkpoint(tmp_path):
     assert np.allclose(r1, r2, rtol=1e-6)
 
 
+def test_label_semantics_through_the_wrapper():
+    from tests.test_host_cpu import check_label_semantics_through_the_wrapper
+    check_label_semantics_through_the_wrapper(build_net)
+
+
+def test_predict_with_truncated_depth_needs_a_matching_posterior():
+    """predict(x, depth=k) with the full-length posterior: the reference's (q * preds) broadcast raises; so do we
+    (the kernel would otherwise use an unnormalised prefix of q)."""
+    c = Case("c2_boston")
+    net = build_net(c)
+    net.fit(c.t("x"), c.y())
+    with pytest.raises(RuntimeError):
+        net.predict(c.t("x"), depth=3)
+
+
 def test_o2_regression_raises_like_the_reference():
     from dun_amd.probability import depth_categorical, homo_Gauss_mloglike
     with pytest.raises(RuntimeError):
