@@ -8,6 +8,8 @@
 // bitwise reproducible run to run (no float atomics).
 #include <math.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace dun {
@@ -1137,6 +1139,67 @@ extern "C" int dun_elbo_gauss(const float* act, const float* y, const float* log
     DUN_REQUIRE(ws_doubles >= dun_elbo_gauss_workspace_doubles(D, B), "dun_elbo_gauss: workspace too small");
     return elbo_gauss_impl(act, y, log_std, q_logits, logprior, prior_ll, D, B, N_train, beta, eps, dact, result, ws,
                            stream, "dun_elbo_gauss");
+}
+
+// ---- the same objective for callers that cannot allocate (no counterpart in the reference) --------------------------
+// Code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc cannot bring a workspace.
+// dun_elbo_gauss_static is dun_elbo_gauss with the per-workgroup partial sums in a file-scope device array instead of
+// the `ws` argument.  Every GPU the library runs on holds its own copy of the array (512 KiB, until the process
+// ends) at its own address: the address is looked up once per device with hipGetSymbolAddress -- in host code the
+// array's NAME is only a stand-in, never a device address -- and only that pointer is handed to kernels.
+// Nothing in the array has to start at zero: the pass writes every [depth][workgroup] slot the finalisation reads.
+// Calls on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race.
+constexpr size_t STATIC_SCRATCH_DOUBLES = 65536;
+static __device__ __align__(256) double scratch[STATIC_SCRATCH_DOUBLES];
+constexpr int STATIC_MAX_DEVICES = 64;
+static double* g_scratch_ptr[STATIC_MAX_DEVICES];  // device address of `scratch` on each device, 0 = not looked up yet
+static std::mutex g_scratch_mutex;
+
+// the current device's copy of the array; looked up (and checked) on the first call per device
+static int static_scratch(double** out, const char* who) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        set_error("%s: hipGetDevice failed: %s", who, hipGetErrorString(e));
+        return DUN_ERR_LAUNCH;
+    }
+    DUN_REQUIRE(dev >= 0 && dev < STATIC_MAX_DEVICES, "%s: device ordinal %d outside [0,%d)", who, dev,
+                STATIC_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr) {
+            set_error("%s: hipGetSymbolAddress(scratch) failed on device %d: %s", who, dev, hipGetErrorString(e));
+            return DUN_ERR_LAUNCH;
+        }
+        g_scratch_ptr[dev] = static_cast<double*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return DUN_OK;
+}
+
+extern "C" int dun_static_init(void) {
+    double* p = nullptr;
+    return static_scratch(&p, "dun_static_init");
+}
+
+extern "C" size_t dun_elbo_gauss_static_max_doubles(void) { return STATIC_SCRATCH_DOUBLES; }
+
+extern "C" int dun_elbo_gauss_static(const float* act, const float* y, const float* log_std, const float* q_logits,
+                                     const float* logprior, const float* prior_ll, int D, int B, double N_train,
+                                     double beta, double eps, float* dact, float* result, dun_stream_t stream) {
+    DUN_REQUIRE(D > 0 && B > 0, "dun_elbo_gauss_static: empty input D=%d B=%d", D, B);
+    DUN_REQUIRE(D <= FINALIZE_FUSED_MAX_D, "dun_elbo_gauss_static: D=%d > %d", D, FINALIZE_FUSED_MAX_D);
+    const size_t need = dun_elbo_gauss_workspace_doubles(D, B);
+    DUN_REQUIRE(need <= STATIC_SCRATCH_DOUBLES,
+                "dun_elbo_gauss_static: D=%d x B=%d needs %zu partial sums, the built-in scratch holds %zu "
+                "(use dun_elbo_gauss with a workspace)", D, B, need, (size_t)STATIC_SCRATCH_DOUBLES);
+    double* ws = nullptr;
+    int rc = static_scratch(&ws, "dun_elbo_gauss_static");
+    if (rc) return rc;
+    return elbo_gauss_impl(act, y, log_std, q_logits, logprior, prior_ll, D, B, N_train, beta, eps, dact, result, ws,
+                           stream, "dun_elbo_gauss_static");
 }
 
 extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std,

@@ -7,7 +7,8 @@
  * All pointers are DEVICE pointers unless a comment says host.  All tensors are dense, row-major fp32 unless
  * stated.  Every entry returns DUN_OK (0) or an error code; dun_last_error() gives the message.  No entry
  * allocates or frees device memory or synchronises the device: scratch comes in through workspace arguments
- * and kernels are enqueued on the hipStream_t passed as `stream`.
+ * (dun_elbo_gauss_static: a fixed array inside the library) and kernels are enqueued on the hipStream_t passed
+ * as `stream`, which must belong to the current device.
  *
  * Citations are file:line in the reference repository.
  */
@@ -105,6 +106,20 @@ size_t dun_elbo_gauss_workspace_doubles(int D, int B);
 int dun_elbo_gauss(const float* act, const float* y, const float* log_std, const float* q_logits,
                    const float* logprior, const float* prior_ll, int D, int B, double N_train, double beta, double eps,
                    float* dact, float* result, double* ws, size_t ws_doubles, dun_stream_t stream);
+
+/* dun_elbo_gauss for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc, which cannot bring the `ws` argument.  The partial
+ * sums live in a device array inside the library instead: 512 KiB per GPU, held until the process ends; inputs with
+ * D * dun_ll_num_partials(B, 1) > dun_elbo_gauss_static_max_doubles() (= 65536; e.g. D = 51 up to B = 5.2 million rows)
+ * are rejected with DUN_ERR_INVALID.  The call allocates and frees nothing; results are bit-identical to
+ * dun_elbo_gauss.  All calls on one GPU share the array: calls that overlap on one GPU (several streams or threads)
+ * race -- serialise them.  dun_static_init() looks up the current device's copy of the array (optional: the first
+ * dun_elbo_gauss_static call on a device does it otherwise; call it before a graph capture begins). */
+int dun_static_init(void);
+size_t dun_elbo_gauss_static_max_doubles(void);
+int dun_elbo_gauss_static(const float* act, const float* y, const float* log_std, const float* q_logits,
+                          const float* logprior, const float* prior_ll, int D, int B, double N_train, double beta,
+                          double eps, float* dact, float* result, dun_stream_t stream);
 
 /* Depth-marginal prediction, replaces depth_categorical.marginalise_d_predict (src/probability.py:188-208)
  * and, when y != NULL, the train/eval metrics of src/DUN/training_wrappers.py:76-87, 101-113, 231-242.
