@@ -342,6 +342,53 @@ def image_case():
         print("wrote", tag, "fit ret", rets[-1], "D", D)
 
 
+def image50_case():
+    """The C4 / C5 constructors themselves: ResNet-50 DUN, start_depth=1, end_depth=13 (D = 12 exits), 10 classes,
+    1x3 stem (experiments/image/train_DUN.py:45-48, 103-139), at batch 4 on MNIST- and CIFAR-shaped inputs.  The
+    26 M weights are not stored: the torch seed pins them, fingerprints of a few tensors check the draw order."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.DUN.stochastic_img_resnets import resnet50
+    for tag, chans, side in (("img_r50_mnist", 1, 28), ("img_r50_cifar", 3, 32)):
+        kw = dict(start_depth=1, end_depth=13, num_classes=10, zero_init_residual=True, initial_conv="1x3",
+                  concat_pool=False, input_chanels=chans, p_drop=0)
+        torch.manual_seed(0)
+        model = resnet50(arch_uncert=True, **kw)
+        D = model.n_layers
+        g = torch.Generator().manual_seed(22)
+        x = torch.randn(4, chans, side, side, generator=g)
+        y = torch.randint(0, 10, (4,), generator=g)
+        pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=False)
+        pm.q_logits.data = 0.2 * torch.randn(D, generator=g)
+        N = 60000 if chans == 1 else 50000
+        net = quiet(DUN_VI, model, pm, N, lr=0.1, momentum=0.9, weight_decay=1e-4, cuda=False, regression=False)
+        out = {"meta": json.dumps(dict(kw=kw, shape=[4, chans, side, side], D=D, N=N, lr=0.1, momentum=0.9, wd=1e-4,
+                                       channel_list=[int(c) for c in model.channel_list])),
+               "x": npy(x), "y": npy(y), "q_logits0": npy(pm.q_logits)}
+        out["n_params"] = np.array(sum(p.numel() for p in model.parameters()))
+        out["keys"] = np.array(sorted(model.state_dict().keys()))
+        sd = model.state_dict()
+        for k in ("conv1.0.weight", "layer_list.0.conv1.weight", "layer_list.8.conv3.weight", "layer_list.15.conv2.weight",
+                  "adapt0.0.weight", "adapt1.0.weight", "adapt2.0.weight", "output_block.weight", "output_block.bias"):
+            out["w/" + k] = npy(sd[k]).ravel()[:64]
+        m2 = copy.deepcopy(model)
+        m2.train()
+        act = m2.forward(x)
+        act.retain_grad()
+        ELBO = pm.estimate_ELBO(m2.get_w_prior_loglike(), act, y, net.f_neg_loglike, net.N_train, Beta=1)
+        (-ELBO / net.N_train).backward()
+        out["act_vec"], out["ELBO"], out["g/act_vec"] = npy(act), npy(ELBO), npy(act.grad)
+        out["g/output_block.weight"] = npy(m2.output_block.weight.grad)
+        out["g/output_block.bias"] = npy(m2.output_block.bias.grad)
+        out["g/q_logits"] = npy(pm.q_logits.grad)
+        pm.q_logits.grad = None
+        m2.eval()
+        with torch.no_grad():
+            out["act_eval"] = npy(m2.forward(x))
+        out["fit/ret"] = np.array([net.fit(x, y)], dtype=np.float64)
+        np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+        print("wrote", tag, "D", D, "params", int(out["n_params"]), "fit", out["fit/ret"])
+
+
 def uci_case():
     """A tiny synthetic table in the reference's UCI on-disk layout, read by the reference's load_gap_UCI
     (src/datasets/UCI_gap_loader.py:12-60); raw files and outputs go into uci_small.npz."""
@@ -438,6 +485,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "prior":
         prior_cases()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "image50":
+        image50_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "labels":
         label_cases()
         return
@@ -475,6 +525,7 @@ def main():
     edge_cases()
     head_case()
     image_case()
+    image50_case()
     uci_case()
 
 
