@@ -19,7 +19,7 @@ EXPORTS = [
     "dun_abi_version", "dun_last_error", "dun_ll_num_partials", "dun_ll_gauss", "dun_ll_softmax", "dun_ll_reduce",
     "dun_depth_finalize", "dun_depth_finalize_partials", "dun_elbo_gauss_workspace_doubles", "dun_elbo_gauss",
     "dun_static_init", "dun_elbo_gauss_static_max_doubles", "dun_elbo_gauss_static", "dun_predict_gauss", "dun_predict_softmax", "dun_predict_num_partials", "dun_gemm_f32", "dun_gemm_colstat_tiles",
-    "dun_fc_workspace_floats", "dun_fc_forward", "dun_fc_backward", "dun_fc_input_layer", "dun_fc_block_linear",
+    "dun_fc_workspace_floats", "dun_fc_obj_num_partials", "dun_fc_head_is_fused", "dun_fc_forward", "dun_fc_backward", "dun_fc_input_layer", "dun_fc_block_linear",
     "dun_fc_block_norm", "dun_fc_head", "dun_fc_head_depth", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply", "dun_fc_bwd_block_dx", "dun_fc_bwd_block_dw",
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
 ]
@@ -53,7 +53,10 @@ class FcCtx(C.Structure):
                 ("x", C.c_void_p), ("H", C.c_void_p), ("Z", C.c_void_p),
                 ("bn_mean", C.c_void_p), ("bn_rstd", C.c_void_p), ("bn_sums", C.c_void_p),
                 ("act", C.c_void_p), ("ws", C.c_void_p), ("ws_floats", C.c_size_t),
-                ("dact", C.c_void_p), ("g", FcTensors), ("G", C.c_void_p), ("dU", C.c_void_p)]
+                ("dact", C.c_void_p), ("g", FcTensors), ("G", C.c_void_p), ("dU", C.c_void_p),
+                ("obj_y", C.c_void_p), ("obj_w", C.c_void_p), ("obj_w_is_logits", C.c_int),
+                ("obj_log_std", C.c_void_p), ("obj_inv_batch", C.c_float), ("obj_dact", C.c_void_p),
+                ("obj_partials", C.c_void_p)]
 
 
 _lib = None
@@ -81,6 +84,8 @@ def _declare(lib):
         "dun_gemm_f32": (i, [C.POINTER(GemmDesc), vp]),
         "dun_gemm_colstat_tiles": (i, [i, i]),
         "dun_fc_workspace_floats": (sz, [i, i, i, i, i]),
+        "dun_fc_obj_num_partials": (i, [i, i]),
+        "dun_fc_head_is_fused": (i, [C.POINTER(FcCtx)]),
         "dun_fc_forward": (i, [C.POINTER(FcCtx), vp]),
         "dun_fc_backward": (i, [C.POINTER(FcCtx), vp]),
         "dun_fc_input_layer": (i, [C.POINTER(FcCtx), vp]),

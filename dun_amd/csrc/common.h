@@ -141,6 +141,28 @@ __device__ __forceinline__ float wave_allmax(float v) {
     return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
+constexpr float LOG_SQRT_2PI_F = 0.91893853320467274178f;
+constexpr double LOG_SQRT_2PI_D = 0.91893853320467274178;
+
+// weight of depth d: w[d], or softmax(w)[d] when the caller hands over logits (q = softmax(q_logits)).
+// Every wavefront works it out for itself -- lanes stride over the D logits, max and sum by DPP reductions -- so there
+// is no LDS slot, no barrier and no serial scalar loop in front of the streaming part of a kernel (the first version
+// walked the D logits in a scalar loop, summed in wave 0 and published through LDS behind a barrier: of the 9.6 us the
+// Gaussian pass took at D = 51, B = 65536 that chain was the longest dependent piece).  fp32 throughout, as F.softmax.
+// Call with all 64 lanes active.
+__device__ __forceinline__ float depth_weight(const float* __restrict__ w, int w_is_logits, int D, int d) {
+    if (w == nullptr) return 0.f;
+    if (!w_is_logits) return w[d];
+    const int lane = threadIdx.x & 63;
+    float mx = -INFINITY;
+    for (int i = lane; i < D; i += 64) mx = fmaxf(mx, w[i]);
+    mx = wave_allmax(mx);
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += expf(w[i] - mx);
+    s = wave_allsum(s);
+    return expf(w[d] - mx) / s;
+}
+
 // sum over a workgroup of NT threads (NT multiple of 64, <= 1024); result valid in thread 0.
 // `red` is caller-provided LDS of at least NT/64 elements; the call contains two barriers.
 template <int NT, typename T>

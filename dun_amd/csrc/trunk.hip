@@ -185,6 +185,134 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+// ---- row-owned forms: BatchNorm apply + residual + shared head (+ Gaussian likelihood terms) in one pass -------------
+// The column-owned bn_apply_kernel above cannot produce the head value act[row] = h_out[row,:] . w_out + b: a row is
+// spread over W/256 workgroups there.  Here a WAVEFRONT owns a row: lane l holds columns (j*64 + l)*4 .. +3 of every
+// 256-column chunk j, keeps the per-column BatchNorm scale / mean / shift and its slice of w_out in registers for all
+// the rows it walks, and the row-dot is one DPP reduction per row.  With the head value in a register the likelihood
+// pass of dun_ll_gauss is free: residual y - act, dact = coef_d * residual, and the per-depth sum of squared residuals
+// (fp64 from the wavefront on, one partial per workgroup, fixed order).  So act_vec, dact and the objective's sums
+// come out of the pass that writes h_out, and the 27 GB re-read of H by a separate head kernel disappears.
+struct HeadObj {
+    const float* y;        // [B] or nullptr
+    const float* w;        // [D] depth weights / logits or nullptr
+    int w_is_logits, D, d; // d: depth of the rows of this launch (grid.y adds to it)
+    const float* log_std;
+    float inv_batch;
+    float* dact;           // [D,B] or nullptr
+    double* partials;      // [D,nparts] or nullptr
+    int nparts;
+};
+
+__device__ __forceinline__ float head_obj_coef(const HeadObj& o, int d) {
+    if (o.y == nullptr) return 0.f;
+    const float wd = depth_weight(o.w, o.w_is_logits, o.D, d);
+    const float sigma = fmaxf(expf(o.log_std[0]), 1e-4f);
+    return -(wd * o.inv_batch) / (sigma * sigma);
+}
+
+// one row's head value -> act, dact, running sum of squared residuals (all lanes hold `a`; lane 0 stores)
+__device__ __forceinline__ void head_obj_row(const HeadObj& o, int d, int B, int row, float a, float coef, int lane,
+                                             float* __restrict__ act_d, double& acc) {
+    if (lane == 0) act_d[row] = a;
+    if (o.y) {
+        const float r = o.y[row] - a;
+        if (lane == 0 && o.dact) o.dact[(size_t)d * B + row] = coef * r;
+        acc += (double)(r * r);
+    }
+}
+
+__device__ __forceinline__ void head_obj_finish(const HeadObj& o, int d, double acc, double* red) {
+    if (o.partials == nullptr) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) red[wv] = acc;  // (every lane of a wavefront holds the same sum)
+    __syncthreads();
+    if (threadIdx.x == 0) o.partials[(size_t)d * o.nparts + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int NCH, bool NT>
+__global__ __launch_bounds__(256) void bn_apply_head_kernel(const float* __restrict__ Z, const float* __restrict__ Hin,
+                                                            float* __restrict__ Hout, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int stat_is_var, float eps,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int B, int residual,
+                                                            const float* __restrict__ w_out,
+                                                            const float* __restrict__ b_out, float* __restrict__ act_d,
+                                                            HeadObj o) {
+    __shared__ double red[4];
+    constexpr int W = NCH * 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    f32x4 sc[NCH], mu[NCH], sh[NCH], wo[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), st = *reinterpret_cast<const f32x4*>(rstd + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[j][e] = g[e] * (stat_is_var ? 1.f / sqrtf(st[e] + eps) : st[e]);
+        mu[j] = *reinterpret_cast<const f32x4*>(mean + c);
+        sh[j] = *reinterpret_cast<const f32x4*>(beta + c);
+        wo[j] = *reinterpret_cast<const f32x4*>(w_out + c);
+    }
+    const float coef = head_obj_coef(o, o.d);
+    const float b0 = b_out[0];
+    double acc = 0.0;
+    for (int row = wave; row < B; row += nwaves) {
+        const size_t off = (size_t)row * W + lane * 4;
+        f32x4 z[NCH], h[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) z[j] = ld4_stream<NT>(Z + off + j * 256);
+        if (residual) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) h[j] = ld4_stream<NT>(Hin + off + j * 256);
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            f32x4 v;
+            // (z - mean) first, then scale: see bn_apply_kernel
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (z[j][e] - mu[j][e]) * sc[j][e] + sh[j][e];
+            if (residual) v += h[j];
+            st4_stream<NT>(Hout + off + j * 256, v);
+            dot += (v[0] * wo[j][0] + v[1] * wo[j][1]) + (v[2] * wo[j][2] + v[3] * wo[j][3]);
+        }
+        head_obj_row(o, o.d, B, row, wave_allsum(dot) + b0, coef, lane, act_d, acc);
+    }
+    head_obj_finish(o, o.d, acc, red);
+}
+
+// The shared head alone (O == 1) with the same likelihood epilogue: depth blockIdx.y of H [.,B,K]; any K.
+template <bool VEC, bool NT>
+__global__ __launch_bounds__(256) void head_obj_kernel(const float* __restrict__ H, const float* __restrict__ w_out,
+                                                       const float* __restrict__ b_out, int B, int K,
+                                                       float* __restrict__ act, HeadObj o) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int dl = blockIdx.y, d = o.d + dl;  // dl: depth inside this launch's H / act, d: global depth (weights, sums)
+    const float* Hd = H + (size_t)dl * B * K;
+    float* act_d = act + (size_t)dl * B;
+    const float coef = head_obj_coef(o, d);
+    const float b0 = b_out[0];
+    double acc = 0.0;
+    for (int row = wave; row < B; row += nwaves) {
+        const float* h = Hd + (size_t)row * K;
+        float dot = 0.f;
+        if (VEC) {
+            for (int k = lane * 4; k < K; k += 256) {
+                const f32x4 hv = ld4_stream<NT>(h + k), wv = *reinterpret_cast<const f32x4*>(w_out + k);
+                dot += (hv[0] * wv[0] + hv[1] * wv[1]) + (hv[2] * wv[2] + hv[3] * wv[3]);
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) dot += h[k] * w_out[k];
+        }
+        // (dact / partials are indexed by the global depth; act_d is already offset)
+        head_obj_row(o, d, B, row, wave_allsum(dot) + b0, coef, lane, act_d, acc);
+    }
+    head_obj_finish(o, d, acc, red);
+}
+
 // per-slab column sums of g and g*xhat (xhat = (z-mean)*rstd): partials [2][P][W]
 template <int VW, bool NT = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ Z,
@@ -393,6 +521,61 @@ static int check_ctx(const dun_fc_ctx* c, const char* who) {
                 "%s: workspace too small", who);
     DUN_REQUIRE(aligned16(c->ws), "%s: workspace must be 16-byte aligned", who);
     DUN_REQUIRE(!c->train || c->depth == 0 || (c->bn_mean && c->bn_rstd && c->bn_sums), "%s: train mode needs bn_mean/bn_rstd/bn_sums", who);
+    if (c->obj_y) {
+        DUN_REQUIRE(c->O == 1, "%s: the likelihood pass inside the head needs one output dimension (O=%d)", who, c->O);
+        DUN_REQUIRE(c->obj_log_std && c->obj_partials, "%s: obj_y without obj_log_std / obj_partials", who);
+        DUN_REQUIRE(!c->obj_w || c->obj_dact, "%s: depth weights without obj_dact", who);
+    }
+    return DUN_OK;
+}
+
+static inline int obj_nparts(int B) {
+    const int n = ceil_div(B, 32);  // four wavefronts per workgroup: >= 8 rows per wavefront up to 512 workgroups
+    return n < 1 ? 1 : (n > 512 ? 512 : n);
+}
+
+static HeadObj make_obj(const dun_fc_ctx* c, int d) {
+    HeadObj o;
+    memset(&o, 0, sizeof(o));
+    o.D = c->depth + 1;
+    o.d = d;
+    o.nparts = obj_nparts(c->B);
+    if (c->obj_y && c->O == 1) {
+        o.y = c->obj_y;
+        o.w = c->obj_w;
+        o.w_is_logits = c->obj_w_is_logits;
+        o.log_std = c->obj_log_std;
+        o.inv_batch = c->obj_inv_batch;
+        o.dact = c->obj_w ? c->obj_dact : nullptr;
+        o.partials = c->obj_partials;
+    }
+    return o;
+}
+
+// block_norm(i) also yields act[i+1] (and the likelihood terms): row-owned pass, see bn_apply_head_kernel
+static bool head_fused(const dun_fc_ctx* c) {
+    if (c->O != 1 || c->W % 256 != 0 || c->W > 2048 || c->depth == 0) return false;
+    const bool stats_ok = c->train ? (aligned16(c->bn_mean) && aligned16(c->bn_rstd))
+                                   : (aligned16(c->running_mean) && aligned16(c->running_var));
+    return stats_ok && aligned16(c->H) && aligned16(c->Z) && aligned16(c->p.w_out) && aligned16(c->p.gamma) &&
+           aligned16(c->p.beta);
+}
+
+// shared head (O == 1) over `ndepth` depths starting at depth d0, with the likelihood epilogue when the context asks
+static int head_obj(const dun_fc_ctx* c, int d0, int ndepth, hipStream_t s) {
+    const float* H = c->H + (size_t)d0 * c->B * c->W;
+    float* act = c->act + (size_t)d0 * c->B;
+    const HeadObj o = make_obj(c, d0);
+    const dim3 grid(obj_nparts(c->B), ndepth);
+    const bool vec = c->W % 4 == 0 && aligned16(H) && aligned16(c->p.w_out);
+    const bool nt = stream_nt((size_t)ndepth * c->B * c->W * 4);
+    if (vec && nt)
+        hipLaunchKernelGGL((head_obj_kernel<true, true>), grid, dim3(256), 0, s, H, c->p.w_out, c->p.b_out, c->B, c->W, act, o);
+    else if (vec)
+        hipLaunchKernelGGL((head_obj_kernel<true, false>), grid, dim3(256), 0, s, H, c->p.w_out, c->p.b_out, c->B, c->W, act, o);
+    else
+        hipLaunchKernelGGL((head_obj_kernel<false, false>), grid, dim3(256), 0, s, H, c->p.w_out, c->p.b_out, c->B, c->W, act, o);
+    DUN_LAUNCH_CHECK();
     return DUN_OK;
 }
 
@@ -473,6 +656,26 @@ static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream
     const float* beta = c->p.beta + (size_t)i * W;
     const int rpb = 32;
     const int nt = stream_nt((size_t)B * W * 4) ? 1 : 0;  // [B,W] planes beyond the Infinity Cache are streamed
+    if (head_fused(c)) {
+        const HeadObj o = make_obj(c, i + 1);
+        float* act_d = c->act + (size_t)(i + 1) * B;
+        const dim3 grid(obj_nparts(B));
+#define BAH(N)                                                                                                         \
+    case N:                                                                                                            \
+        if (nt)                                                                                                        \
+            hipLaunchKernelGGL((bn_apply_head_kernel<N, true>), grid, dim3(256), 0, s, Z, hin, hout, mean, stat, is_var, \
+                               c->bn_eps, gamma, beta, B, c->residual, c->p.w_out, c->p.b_out, act_d, o);               \
+        else                                                                                                           \
+            hipLaunchKernelGGL((bn_apply_head_kernel<N, false>), grid, dim3(256), 0, s, Z, hin, hout, mean, stat, is_var, \
+                               c->bn_eps, gamma, beta, B, c->residual, c->p.w_out, c->p.b_out, act_d, o);               \
+        break;
+        switch (W / 256) {
+            BAH(1) BAH(2) BAH(3) BAH(4) BAH(5) BAH(6) BAH(7) BAH(8)
+        }
+#undef BAH
+        DUN_LAUNCH_CHECK();
+        return DUN_OK;
+    }
     if (vec4_ok(W, Z, hin, hout)) {
         if (nt)
             hipLaunchKernelGGL((bn_apply_kernel<4, true>), dim3(ceil_div(W, CX * 4), ceil_div(B, rpb)), dim3(256), 0, s, Z,
@@ -488,7 +691,9 @@ static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream
     return DUN_OK;
 }
 
+// the shared head over every depth at once; with the likelihood epilogue when the context asks for it (O == 1)
 static int head(const dun_fc_ctx* c, hipStream_t s) {
+    if (c->obj_y && c->O == 1) return head_obj(c, 0, c->depth + 1, s);
     return head_forward(c->H, c->p.w_out, c->p.b_out, (c->depth + 1) * c->B, c->W, c->O, c->act, s);
 }
 
@@ -645,6 +850,10 @@ static size_t base_workspace_floats(int B, int W, int O, int L) {
     return (m + 64 + 63) / 64 * 64;
 }
 
+extern "C" int dun_fc_obj_num_partials(int B, int O) { return (B > 0 && O == 1) ? obj_nparts(B) : 0; }
+
+extern "C" int dun_fc_head_is_fused(const dun_fc_ctx* c) { return (c != nullptr && head_fused(c)) ? 1 : 0; }
+
 extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
     (void)din;
     return base_workspace_floats(B, W, O, L) + sn_extra_ws_floats(B, W, L);
@@ -672,6 +881,7 @@ extern "C" int dun_fc_head_depth(const dun_fc_ctx* c, int d, dun_stream_t stream
     int rc = check_ctx(c, "dun_fc_head_depth");
     if (rc) return rc;
     DUN_REQUIRE(d >= 0 && d <= c->depth, "dun_fc_head_depth: depth %d outside [0,%d]", d, c->depth);
+    if (c->O == 1 && (c->obj_y || head_fused(c))) return head_obj(c, d, 1, STREAM);
     return head_forward(c->H + (size_t)d * c->B * c->W, c->p.w_out, c->p.b_out, c->B, c->W, c->O,
                         c->act + (size_t)d * c->B * c->O, STREAM);
 }
@@ -684,11 +894,13 @@ extern "C" int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream) {
             if ((rc = sn_forward_block(c, i, STREAM))) return rc;
         return head(c, STREAM);
     }
+    const bool fused = head_fused(c);  // block_norm(i) writes act[i+1] itself: only depth 0 needs the head kernel
+    if (fused && (rc = head_obj(c, 0, 1, STREAM))) return rc;
     for (int i = 0; i < c->depth; ++i) {
         if ((rc = block_linear(c, i, STREAM, /*reduce_stats=*/false))) return rc;
         if ((rc = block_norm(c, i, (double)c->B, STREAM, /*from_partials=*/c->train != 0))) return rc;
     }
-    return head(c, STREAM);
+    return fused ? DUN_OK : head(c, STREAM);
 }
 
 extern "C" int dun_fc_bwd_begin(const dun_fc_ctx* c, dun_stream_t stream) {

@@ -33,6 +33,7 @@ class FcBuffers(object):
         self.dU = None
         self.x = None
         self.dact = None
+        self._obj = None
         c = L.FcCtx()
         c.B, c.din, c.W, c.O, c.L = B, din, W, O, Lyr
         c.residual, c.train, c.depth = int(model.residual), int(train), depth
@@ -64,6 +65,33 @@ class FcBuffers(object):
     def set_dact(self, dact):
         self.dact = dact
         self.c.dact = L.f32(dact)
+
+    def set_objective(self, spec):
+        """Fold the Gaussian likelihood pass into the head kernels of the next forward (spec: probability.HeadObjective,
+        or None for a plain forward).  Its outputs are fresh tensors per forward, handed over through the spec."""
+        c = self.c
+        if spec is None:
+            c.obj_y = c.obj_w = c.obj_log_std = c.obj_dact = c.obj_partials = None
+            self._obj = None
+            return
+        D, B, O = self._act_shape
+        nparts = L.lib().dun_fc_obj_num_partials(B, O)
+        if nparts <= 0:
+            raise RuntimeError("the likelihood pass inside the head needs one output dimension")
+        dev = self.H.device
+        spec.partials = torch.empty(D, nparts, device=dev, dtype=torch.float64)
+        spec.dact = torch.empty(self._act_shape, device=dev, dtype=torch.float32) if spec.w is not None else None
+        c.obj_y, c.obj_log_std = L.f32(spec.y), L.f32(spec.log_std)
+        c.obj_w = None if spec.w is None else L.f32(spec.w)
+        c.obj_w_is_logits, c.obj_inv_batch = int(spec.w_is_logits), float(spec.inv_batch)
+        c.obj_dact = None if spec.dact is None else L.f32(spec.dact)
+        c.obj_partials = L.ptr(spec.partials)
+        self._obj = spec  # keeps the tensors behind the raw pointers alive until the next forward
+
+    @property
+    def head_fused(self):
+        """block_norm(i) also writes act[i+1] (dun_fc_head_is_fused): a staged caller runs fc_head_depth for depth 0 only."""
+        return bool(L.lib().dun_fc_head_is_fused(C.byref(self.c)))
 
 
 class HipBackend(object):
@@ -113,6 +141,16 @@ class HipBackend(object):
             sums = torch.empty(D, device=dev, dtype=torch.float64)
             L.check(lib.dun_ll_reduce(L.ptr(partials), D, nparts, L.ptr(sums), s), "dun_ll_reduce")
         return sums, dact, ll
+
+    def ll_reduce(self, partials):
+        """sums[d] = sum_j partials[d, j] (what a batch-sharded job all-reduces before depth_finalize)."""
+        D, nparts = partials.shape
+        if nparts == 1:
+            return partials.view(D)
+        sums = torch.empty(D, device=partials.device, dtype=torch.float64)
+        L.check(L.lib().dun_ll_reduce(L.ptr(partials), D, nparts, L.ptr(sums), L.stream_ptr(partials.device)),
+                "dun_ll_reduce")
+        return sums
 
     def depth_finalize(self, sums, gaussian, q_logits, logprior, prior_ll, log_std, N_train, batch, beta, eps,
                        objective, partials=False):

@@ -75,6 +75,18 @@ def _prior_vec(prior_loglikes, D, ref):
     return p.contiguous()
 
 
+class HeadObjective(object):
+    """Request to a trunk's forward: run the Gaussian likelihood pass inside the head kernels (the head value of a row
+    is in a register when it is written, so y - act, d loss / d act and the per-depth sums of squared residuals cost
+    no further pass over act_vec).  The forward fills ``partials`` (double [D, nparts]) and, when depth weights were
+    given, ``dact`` ([D,B,1]); ``_fused(..., head_pass=spec)`` then skips its own streaming pass."""
+    __slots__ = ("y", "w", "w_is_logits", "log_std", "inv_batch", "partials", "dact")
+
+    def __init__(self, y, w, w_is_logits, log_std, inv_batch):
+        self.y, self.w, self.w_is_logits, self.log_std, self.inv_batch = y, w, w_is_logits, log_std, inv_batch
+        self.partials = self.dact = None
+
+
 class FusedOut(object):
     """Result of depth_categorical.fused_objective (all tensors stay on the device)."""
     __slots__ = ("res", "D", "dact", "sums")
@@ -97,8 +109,20 @@ class FusedOut(object):
     loglike_sum = property(lambda s: s._arr(4))  # sum_b loglike[d,b]
 
 
+def head_objective_spec(y, f_neg_loglike, objective, q_logits, batch, dist=None, want_grad=True):
+    """A HeadObjective for this step, or None where the fusion does not apply (classification; more than one output)."""
+    if not isinstance(f_neg_loglike, homo_Gauss_mloglike) or f_neg_loglike.log_std.numel() != 1:
+        return None
+    if y.dim() > 2 or (y.dim() == 2 and y.shape[1] != 1) or y.shape[0] != batch:
+        return None
+    gb = batch if dist is None else dist.global_batch(batch)
+    yy = y.detach().to(torch.float32).contiguous()
+    w = q_logits.detach() if (objective == OBJ_VI and want_grad) else None
+    return HeadObjective(yy, w, True, f_neg_loglike.log_std.detach(), 1.0 / gb)
+
+
 def _fused(act_vec, y, f_neg_loglike, N_train, logprior, prior_loglikes, objective, q_logits=None, beta=1.0,
-           eps=1e-35, want_grad=True, dist=None, want_ll=False):
+           eps=1e-35, want_grad=True, dist=None, want_ll=False, head_pass=None):
     be = kernels.backend()
     regression, log_std = _likelihood_kind(f_neg_loglike)
     act = act_vec.detach()
@@ -125,15 +149,27 @@ def _fused(act_vec, y, f_neg_loglike, N_train, logprior, prior_loglikes, objecti
         dist.all_reduce(s_)
         return be.depth_finalize(s_, regression, q_, logprior, prior, ls, N_train, gb, beta, eps, obj), s_
 
+    # the trunk's head kernels already ran the pass (HeadObjective): its partial sums (and dact) are used as they are
+    from_head = head_pass is not None and head_pass.partials is not None and regression and not want_ll
+
+    def head_sums():
+        return head_pass.partials if local else be.ll_reduce(head_pass.partials)
+
     if objective == OBJ_VI:
         # q is known before the pass: likelihood, its reduction and dact in ONE sweep over act_vec
-        sums, dact, ll = be.ll_pass(act, yy, regression, ls, ql if want_grad else None, True, 1.0 / gb,
-                                    want_dact=want_grad, want_ll=want_ll, reduce=not local)
+        if from_head and (head_pass.dact is not None or not want_grad):
+            sums, dact = head_sums(), (head_pass.dact if want_grad else None)
+        else:
+            sums, dact, ll = be.ll_pass(act, yy, regression, ls, ql if want_grad else None, True, 1.0 / gb,
+                                        want_dact=want_grad, want_ll=want_ll, reduce=not local)
         res, sums = finalize(sums, ql, OBJ_VI)
     else:
         # the exact posterior needs the complete (all-reduced) per-depth sums first: two sweeps
-        sums, _, ll = be.ll_pass(act, yy, regression, ls, None, False, 1.0 / gb, want_dact=False, want_ll=want_ll,
-                                 reduce=not local)
+        if from_head:
+            sums = head_sums()
+        else:
+            sums, _, ll = be.ll_pass(act, yy, regression, ls, None, False, 1.0 / gb, want_dact=False, want_ll=want_ll,
+                                     reduce=not local)
         res, sums = finalize(sums, None, OBJ_MLL)
         dact = None
         if want_grad:
@@ -245,10 +281,15 @@ class depth_categorical(nn.Module):
             return out, std
         return out
 
-    def fused_objective(self, prior_loglikes, act_vec, y, f_neg_loglike, N_train, want_grad=True, want_ll=False):
+    def fused_objective(self, prior_loglikes, act_vec, y, f_neg_loglike, N_train, want_grad=True, want_ll=False,
+                        head_pass=None):
         """Exact marginal over depth + its backward (see module docstring).  -> FusedOut"""
         return _fused(act_vec, y, f_neg_loglike, N_train, self.logprior, prior_loglikes, OBJ_MLL,
-                      want_grad=want_grad, dist=self._dist, want_ll=want_ll)
+                      want_grad=want_grad, dist=self._dist, want_ll=want_ll, head_pass=head_pass)
+
+    def head_objective(self, y, f_neg_loglike, batch, want_grad=True):
+        """HeadObjective for the exact-marginal objective (sums only: the posterior is not known before the pass)."""
+        return head_objective_spec(y, f_neg_loglike, OBJ_MLL, None, batch, self._dist, want_grad)
 
 
 class _Elbo(torch.autograd.Function):
@@ -312,11 +353,15 @@ class depth_categorical_VI(depth_categorical):
         return _Elbo.apply(act_vec, self.q_logits, log_std, prior_loglikes, y, f_neg_loglike, N_train, self, Beta)
 
     def fused_objective(self, prior_loglikes, act_vec, y, f_neg_loglike, N_train, want_grad=True, want_ll=False,
-                        Beta=1):
+                        Beta=1, head_pass=None):
         """ELBO + d(-ELBO/N)/d(act, q_logits, log_std) in a single pass over act_vec.  -> FusedOut"""
         return _fused(act_vec, y, f_neg_loglike, N_train, self.logprior, prior_loglikes, OBJ_VI,
                       q_logits=self.q_logits, beta=Beta, eps=self.eps, want_grad=want_grad, dist=self._dist,
-                      want_ll=want_ll)
+                      want_ll=want_ll, head_pass=head_pass)
+
+    def head_objective(self, y, f_neg_loglike, batch, want_grad=True):
+        """HeadObjective for the ELBO: q is known before the pass, so the head kernels also write d loss / d act."""
+        return head_objective_spec(y, f_neg_loglike, OBJ_VI, self.q_logits, batch, self._dist, want_grad)
 
     def q_predict(self, act_vec, depth=None, softmax=False):
         return depth_categorical.marginalise_d_predict(act_vec, self.get_q_probs(), depth=depth, softmax=softmax)

@@ -25,8 +25,8 @@ class _FcForward(torch.autograd.Function):
     flat gradient buffer (``p.grad`` views), not returned to autograd, and overwrite what was there."""
 
     @staticmethod
-    def forward(ctx, model, x, depth, *params):
-        buf = model._run_forward(x, depth, True)
+    def forward(ctx, model, x, depth, objective, *params):
+        buf = model._run_forward(x, depth, True, objective)
         ctx.model, ctx.buf = model, buf
         # The returned tensor becomes this node's output (grad_fn -> node -> parameters -> model).  Left in the buffer
         # object it would close model -> buffers -> act -> node -> model through the C++ autograd graph, which
@@ -41,7 +41,7 @@ class _FcForward(torch.autograd.Function):
             raise RuntimeError("the trunk's backward ran already (its buffers are reused by the next forward)")
         ctx.model = ctx.buf = None  # a kept act_vec does not pin the buffers
         model._run_backward(buf, dact)
-        return (None, None, None) + (None,) * len(model._param_list)
+        return (None, None, None, None) + (None,) * len(model._param_list)
 
 
 class arq_uncert_fc_resnet(nn.Module):
@@ -208,7 +208,9 @@ class arq_uncert_fc_resnet(nn.Module):
             self._fc_cache[key] = buf
         return buf
 
-    def _run_forward(self, x, depth, train):
+    supports_head_objective = True  # forward(x, objective=HeadObjective): likelihood pass inside the head kernels
+
+    def _run_forward(self, x, depth, train, objective=None):
         if x.dim() != 2 or x.shape[1] != self.input_dim:
             raise RuntimeError("expected x of shape [B, %d], got %s" % (self.input_dim, tuple(x.shape)))
         be = kernels.backend()
@@ -216,26 +218,33 @@ class arq_uncert_fc_resnet(nn.Module):
         buf = self._get_buffers(x.shape[0], depth, train)
         buf.new_act()
         buf.set_input(x)
+        buf.set_objective(objective if self.output_dim == 1 else None)
         dist = self._dist
         if dist is None or not (train and dist.sync_bn) or depth == 0:
             be.fc_forward(buf)
         else:
-            # the shared head runs depth by depth on the hidden state block i started from (still in the Infinity Cache
-            # behind the GEMM that just read it); with dist.async_forward_bn it runs UNDER the exchange of block i
+            # Staged at the BatchNorm exchanges.  Where block_norm(i) writes act[i+1] itself (row-owned BatchNorm apply
+            # + head: buf.head_fused) only depth 0 needs the head kernel; otherwise the shared head runs depth by depth
+            # on the hidden state block i started from, with dist.async_forward_bn UNDER the exchange of block i
             gb = dist.global_batch(x.shape[0])
+            fused = buf.head_fused
             be.fc_input_layer(buf)
+            if fused:
+                be.fc_head_depth(buf, 0)
             for i in range(depth):
                 be.fc_block_linear(buf, i)
-                if dist.async_forward_bn:
+                if dist.async_forward_bn and not fused:
                     h = dist.all_reduce_async(buf.bn_sums)
                     be.fc_head_depth(buf, i)
                     if h is not None:
                         h.wait()
                 else:
                     dist.all_reduce(buf.bn_sums)
-                    be.fc_head_depth(buf, i)
+                    if not fused:
+                        be.fc_head_depth(buf, i)
                 be.fc_block_norm(buf, i, gb)
-            be.fc_head_depth(buf, depth)
+            if not fused:
+                be.fc_head_depth(buf, depth)
         if train and depth > 0:
             self.num_batches_tracked[:depth] += 1
         return buf
@@ -284,11 +293,13 @@ class arq_uncert_fc_resnet(nn.Module):
             if p.grad is not g:
                 p.grad = g
 
-    def forward(self, x, depth=None):
+    def forward(self, x, depth=None, objective=None):
+        """act_vec [depth+1, B, O].  ``objective`` (probability.HeadObjective, regression with one output) additionally
+        runs the likelihood pass inside the head kernels and leaves its results in that object."""
         depth = self.n_layers if depth is None else depth
         if self.training and torch.is_grad_enabled():
-            return _FcForward.apply(self, x, depth, *self._param_list)
-        return self._run_forward(x, depth, self.training).act
+            return _FcForward.apply(self, x, depth, objective, *self._param_list)
+        return self._run_forward(x, depth, self.training, objective).act
 
     forward_get_acts = forward
 

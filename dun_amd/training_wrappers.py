@@ -205,11 +205,22 @@ class DUN(BaseNet):
             return None
         return self.model.get_w_prior_loglike(k=None)
 
+    def _forward_with_objective(self, x, y, want_grad=True):
+        """model.forward(x), with the likelihood pass folded into the trunk's head kernels where that applies
+        (regression on an FC trunk): -> (act_vec, HeadObjective or None)."""
+        spec = None
+        if self.regression and getattr(self.model, "supports_head_objective", False):
+            spec = self.prob_model.head_objective(y, self.f_neg_loglike, x.shape[0], want_grad)
+        if spec is None:
+            return self.model.forward(x), None
+        return self.model.forward(x, objective=spec), spec
+
     def _step(self, x, y):
         self.optimizer.zero_grad()
-        act_vec = self.model.forward(x)
+        act_vec, head_pass = self._forward_with_objective(x, y)
         prior_loglikes = self._prior_loglikes()
-        out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train)
+        out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train,
+                                              head_pass=head_pass)
         self._backward(act_vec, prior_loglikes, out)
         self.optimizer.step()
         # this posterior is one iteration behind the parameters: estimated with the acts from before the step
@@ -295,15 +306,16 @@ class DUN(BaseNet):
             cum = None
             for x, y in trainloader:
                 x, y = self._prepare(x, y)
-                act_vec = self.model.forward(x)
+                act_vec, head_pass = self._forward_with_objective(x, y, want_grad=False)
                 gb = x.shape[0] * world
                 if vi:
                     out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, N_train,
-                                                          want_grad=False)
+                                                          want_grad=False, head_pass=head_pass)
                     term = (gb / N_train) * out.objective.double()
                 else:
                     out = depth_categorical.fused_objective(self.prob_model, prior_loglikes, act_vec, y,
-                                                            self.f_neg_loglike, N_train, want_grad=False)
+                                                            self.f_neg_loglike, N_train, want_grad=False,
+                                                            head_pass=head_pass)
                     term = (gb / N_train) * out.joint.double()
                 cum = term if cum is None else cum + term
             return cum
@@ -325,9 +337,10 @@ class DUN_VI(DUN):
 
     def _step(self, x, y):
         self.optimizer.zero_grad()
-        act_vec = self.model.forward(x)
+        act_vec, head_pass = self._forward_with_objective(x, y)
         prior_loglikes = self._prior_loglikes()
-        out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train, Beta=1)
+        out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train, Beta=1,
+                                              head_pass=head_pass)
         self._backward(act_vec, prior_loglikes, out)
         self.optimizer.step()
         self.prob_model.current_posterior = self.prob_model.get_q_probs().detach()

@@ -208,9 +208,27 @@ typedef struct dun_fc_ctx {
     dun_fc_tensors g;    /* gradients, same shapes as p (overwritten, not accumulated) */
     float* G;            /* [B,W] running dL/dh */
     float* dU;           /* [B,W] dL/d(Linear output) of the current block */
+    /* Optional (all NULL / 0 = plain forward): the Gaussian likelihood pass of dun_ll_gauss folded into the head, O == 1.
+     * The head value of a row is in a register when it is written, so y - act, d(-objective/N)/d act and the
+     * per-depth sums of (y - act)^2 cost no further pass over act_vec: SURVEY.md section 7 step 5, replacing the
+     * act_vec round trip between src/DUN/stochastic_fc_models.py:66,69 and src/probability.py:162-174. */
+    const float* obj_y;       /* [B] targets */
+    const float* obj_w;       /* [depth+1] depth weights (see dun_ll_gauss `w`), or NULL: sums only, no dact */
+    int obj_w_is_logits;
+    const float* obj_log_std; /* [1] */
+    float obj_inv_batch;      /* 1 / global batch */
+    float* obj_dact;          /* [depth+1,B] d(-objective/N)/d act, or NULL */
+    double* obj_partials;     /* [depth+1, dun_fc_obj_num_partials(B, O)]: per-workgroup sums of (y - act)^2, the layout
+                                 dun_ll_reduce / dun_depth_finalize_partials take */
 } dun_fc_ctx;
 
 size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L);
+/* Partial sums per depth the head writes when obj_y is set (0: not supported for this shape, i.e. O != 1). */
+int dun_fc_obj_num_partials(int B, int O);
+/* 1 when block_norm(i) also produces act[i+1] (width a multiple of 256 up to 2048, O == 1, 16-byte aligned planes):
+ * BatchNorm apply, residual add, head row-dot and the likelihood terms in ONE pass over the [B,W] plane, so a caller of
+ * the staged entries needs dun_fc_head_depth for depth 0 only. */
+int dun_fc_head_is_fused(const dun_fc_ctx* c);
 
 /* Whole net in one call.  W <= 128 (W % 4 == 0) with B <= 2048 -- the toy / UCI nets of experiments/toy/train_toy.py
  * and experiments/regression -- run one column-owned launch per block (smallnet.hip) instead of the tiled GEMM

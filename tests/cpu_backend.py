@@ -25,6 +25,7 @@ class CpuFcBuffers(object):
         self.bn_rstd = torch.zeros(max(L, 1), W)
         self.bn_sums = torch.zeros(2, W, dtype=torch.float64)
         self.G = self.dU = self.x = self.dact = None
+        self._obj = None
 
     def new_act(self):
         self.act = torch.zeros(self._act_shape)
@@ -39,6 +40,21 @@ class CpuFcBuffers(object):
 
     def set_dact(self, dact):
         self.dact = dact
+
+    def set_objective(self, spec):
+        """Mirror of FcBuffers.set_objective: the heads below fill spec.partials (one partial per depth here) and,
+        with depth weights, spec.dact."""
+        self._obj = spec
+        if spec is not None:
+            D, B, O = self._act_shape
+            assert O == 1
+            spec.partials = torch.zeros(D, 1, dtype=torch.float64)
+            spec.dact = torch.zeros(self._act_shape) if spec.w is not None else None
+
+    @property
+    def head_fused(self):
+        m = self.model
+        return m.output_dim == 1 and m.width % 256 == 0 and m.width <= 2048 and self.depth > 0
 
 
 class CpuBackend(object):
@@ -83,6 +99,9 @@ class CpuBackend(object):
             oh = F.one_hot(ys, C).to(act.dtype).unsqueeze(0)
             dact = -(wt.view(D, 1, 1) * inv_batch) * (oh - lsm.exp()) * ok.view(1, B, 1).to(act.dtype)
         return sums, dact, (llv if want_ll else None)
+
+    def ll_reduce(self, partials):
+        return partials.sum(dim=1)
 
     def depth_finalize(self, sums, gaussian, q_logits, logprior, prior_ll, log_std, N_train, batch, beta, eps,
                        objective, partials=False):
@@ -187,21 +206,41 @@ class CpuBackend(object):
             mean_f, rstd_f = m.running_mean[i], 1.0 / torch.sqrt(m.running_var[i] + m.bn_eps)
         blk = (z - mean_f) * (p["gamma"][i] * rstd_f) + p["beta"][i]
         buf.H[i + 1] = buf.H[i] + blk if m.residual else blk
+        if buf.head_fused:  # the kernels' row-owned pass writes act[i+1] (and the likelihood terms) here
+            self.fc_head_depth(buf, i + 1)
+
+    def _likelihood_terms(self, buf, d):
+        """What the head kernels add when the context carries an objective (dun_fc_ctx.obj_*)."""
+        o = buf._obj
+        if o is None:
+            return
+        r = o.y.reshape(-1) - buf.act[d].reshape(-1)
+        o.partials[d, 0] = (r.double() ** 2).sum()
+        if o.w is not None:
+            wt = F.softmax(o.w.float(), dim=0) if o.w_is_logits else o.w.float()
+            sig = o.log_std.exp().clamp(min=1e-4)
+            o.dact[d] = (-(wt[d] * o.inv_batch) * r / sig ** 2).reshape(o.dact[d].shape)
 
     def fc_head(self, buf):
         p = buf.model.stacked
         buf.act.copy_(F.linear(buf.H, p["w_out"], p["b_out"]))
+        for d in range(buf.depth + 1):
+            self._likelihood_terms(buf, d)
 
     def fc_head_depth(self, buf, d):
         p = buf.model.stacked
         buf.act[d].copy_(F.linear(buf.H[d], p["w_out"], p["b_out"]))
+        self._likelihood_terms(buf, d)
 
     def fc_forward(self, buf):
         self.fc_input_layer(buf)
+        if buf.head_fused:
+            self.fc_head_depth(buf, 0)
         for i in range(buf.depth):
             self.fc_block_linear(buf, i)
             self.fc_block_norm(buf, i, buf.B)
-        self.fc_head(buf)
+        if not buf.head_fused:
+            self.fc_head(buf)
 
     def fc_bwd_begin(self, buf):
         m, g = buf.model, buf.model.stacked_grad

@@ -262,6 +262,60 @@ def test_predict_with_truncated_depth_needs_a_matching_posterior():
         net.predict(c.t("x"), depth=3)
 
 
+@pytest.mark.parametrize("vi", [True, False])
+@pytest.mark.parametrize("din,W,L,B", [(64, 256, 3, 1024), (16, 2048, 2, 640), (7, 768, 2, 333), (13, 100, 10, 512),
+                                       (5, 257, 2, 129), (3, 512, 0, 64), (8, 1024, 1, 40000)])
+def test_likelihood_pass_inside_the_head_matches_the_separate_pass(din, W, L, B, vi):
+    """forward(x, objective=...) -- BatchNorm apply + residual + head + Gaussian likelihood terms in one row-owned pass
+    (widths that are multiples of 256), or the head kernel with the likelihood epilogue (any other width, small nets)
+    -- against forward(x) followed by the streaming pass over act_vec: same act_vec, dact, sums, objective; train and
+    eval mode; and a whole fit step either way lands on the same parameters."""
+    from dun_amd.probability import depth_categorical, depth_categorical_VI
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_resnet
+    from dun_amd.training_wrappers import DUN, DUN_VI
+    D, N = L + 1, 5000
+
+    def make():
+        torch.manual_seed(W + L)
+        model = arq_uncert_fc_resnet(din, 1, W, L)
+        pm = (depth_categorical_VI if vi else depth_categorical)([1.0 / D] * D, cuda=True)
+        net = quiet(DUN_VI if vi else DUN, model, pm, N, lr=1e-3, momentum=0.5, cuda=True, regression=True)
+        g = torch.Generator().manual_seed(B)
+        if vi:
+            pm.q_logits.data.copy_(0.3 * torch.randn(D, generator=g))
+        net.f_neg_loglike.log_std.data.fill_(0.2)
+        return net, torch.randn(B, din, generator=g).cuda(), torch.randn(B, 1, generator=g).cuda()
+
+    net, x, y = make()
+    for train in (True, False):
+        net.model.train(train)
+        rm = net.model.running_mean.clone()
+        with torch.no_grad():
+            act_plain = net.model.forward(x).clone()
+            net.model.running_mean.copy_(rm)  # (a train-mode forward moves the running statistics)
+            plain = net.prob_model.fused_objective(None, act_plain, y, net.f_neg_loglike, N)
+            net.model.running_mean.copy_(rm)
+            spec = net.prob_model.head_objective(y, net.f_neg_loglike, B)
+            assert spec is not None
+            act_fused = net.model.forward(x, objective=spec)
+            fused = net.prob_model.fused_objective(None, act_fused, y, net.f_neg_loglike, N, head_pass=spec)
+        assert spec.partials is not None and (spec.dact is not None) == vi
+        assert rel_err(act_fused.cpu(), act_plain.cpu()) < 2e-6
+        assert rel_err(fused.sums.cpu(), plain.sums.cpu()) < 1e-6
+        assert rel_err(fused.joint.cpu(), plain.joint.cpu()) < 1e-6
+        assert rel_err(fused.objective.cpu(), plain.objective.cpu()) < 1e-6
+        assert rel_err(fused.dact.cpu().view(-1), plain.dact.cpu().view(-1)) < 2e-5
+    # whole steps: the wrapper takes the fused route by itself; switch it off for the other net
+    a, xa, ya = make()
+    b, _, _ = make()
+    b.model.supports_head_objective = False
+    for _ in range(2):
+        ra, rb = a.fit(xa, ya), b.fit(xa, ya)
+        assert np.allclose(ra, rb, rtol=2e-5, equal_nan=True), (ra, rb)
+    assert rel_err(a.model.flat_params.cpu(), b.model.flat_params.cpu()) < 1e-5
+    assert np.allclose(a.eval(xa, ya), b.eval(xa, ya), rtol=1e-5, equal_nan=True)
+
+
 def test_o2_regression_raises_like_the_reference():
     from dun_amd.probability import depth_categorical, homo_Gauss_mloglike
     with pytest.raises(RuntimeError):
