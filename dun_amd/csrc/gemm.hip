@@ -48,6 +48,8 @@ struct GemmP {
     int gridM, gridN;
     int ksplit;   // > 1: blockIdx.y takes K range [y*K/ksplit, (y+1)*K/ksplit) and stores its raw sum to part[y]
     float* part;  // [ksplit][M][N]
+    int gm;       // LDS-DMA kernel: row panels per tile group (1: tiles of one row panel are consecutive)
+    int rinit;    // LDS-DMA kernel: accumulators start from R (loaded under the pipeline prologue), not added at the end
 };
 
 // ---- global -> register staging of one operand tile: 4 x float4 per thread ----
@@ -525,19 +527,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int bm = bid / p.gridN, bn = bid % p.gridN;
+    int bm = bid / p.gridN, bn = bid % p.gridN;
+    if (p.gm > 1) {  // groups of gm row panels, row panel fastest inside a group
+        const int per = p.gm * p.gridN, g = bid / per, r = bid % per;
+        const int rows = min(p.gm, p.gridM - g * p.gm);
+        bm = g * p.gm + r % rows;
+        bn = r / rows;
+    }
     const int m0 = bm * BM, n0 = bn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
 
     f32x16 acc[2][2];
+    if (p.rinit) {
+        // C = R + A B with the accumulators STARTING from the R tile: its loads go out in front of the pipeline prologue
+        // and land under it, instead of a dependent HBM round trip in the epilogue with an empty matrix pipe
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wc * 64 + ni * 32 + li;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    acc[mi][ni][r] = p.R[(size_t)row * p.ldr + col];
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    }
 
     const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * (p.K / p.ksplit) : 0;
     const int nh = (p.ksplit > 1 ? p.K / p.ksplit : p.K) / HK;  // >= 2 (K range % 32 == 0)
@@ -558,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     // pending at the loop entry shares lgkmcnt with the LDS reads, the counter is then no longer in-order for the
     // compiler, and it would wait for lgkmcnt(0) -- i.e. for the prefetch just issued -- at every MFMA group.
     asm volatile("" ::"s"(p.C), "s"(p.bias), "s"(p.R), "s"(p.U), "s"(p.V), "s"(p.colstats), "s"(p.M), "s"(p.N),
-                 "s"(p.ldc), "s"(p.ldr), "s"(p.O), "s"(p.ldv), "s"(p.relu), "s"(p.gridM));
+                 "s"(p.ldc), "s"(p.ldr), "s"(p.O), "s"(p.ldv), "s"(p.relu), "s"(p.gridM), "s"(p.rinit));
 
     float fa[2][2][4], fb[2][2][4];
 #pragma unroll
@@ -618,6 +642,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
         q.C = p.part + (size_t)blockIdx.y * p.M * p.N;
         q.ldc = p.N;
         q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr;
+        gemm_epilogue<true, 2>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    } else if (p.rinit) {
+        GemmP q = p;
+        q.R = nullptr;  // already inside the accumulators
         gemm_epilogue<true, 2>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
     } else {
         gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
@@ -710,6 +738,8 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     p.R = d->R; p.ldr = d->ldr;
     p.U = d->U; p.V = d->V; p.O = d->O; p.ldv = d->ldv;
     p.colstats = d->colstats;
+    p.gm = 1;
+    p.rinit = 0;
     const bool small = small_problem(d->M, d->N);
     const int tile = small ? 64 : BM;
     p.gridM = ceil_div(d->M, tile);
@@ -748,6 +778,16 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
             p.ksplit = (int)ks;
             p.part = d->splitk_ws;
         }
+    }
+    if (dma && p.ksplit == 1) {
+        // A/B hooks.  DUN_GEMM_GM=g: tiles ordered in groups of g row panels (measured at the wide configuration's shapes,
+        // g = 4, 8, 16: no change in any of the three GEMMs -- the kernels are not bound by L2 misses; default 1).
+        // DUN_GEMM_RINIT=0: residual added in the epilogue instead of seeding the accumulators (dX 3.94 -> 3.90 ms with
+        // the seeding, within 10 us of the epilogue-free kernel).
+        static const int env_gm = getenv("DUN_GEMM_GM") ? atoi(getenv("DUN_GEMM_GM")) : 1;
+        static const int env_rinit = getenv("DUN_GEMM_RINIT") ? atoi(getenv("DUN_GEMM_RINIT")) : 1;
+        p.gm = env_gm > 1 ? env_gm : 1;
+        p.rinit = (env_rinit && d->R && !d->bias && !d->relu) ? 1 : 0;
     }
     if (d->a_kcontig) {
         if (d->b_kcontig) return launch_gemm<true, true>(p, vec, dma, small, s);
