@@ -37,7 +37,9 @@ class GemmDesc(C.Structure):
                 ("bias", C.c_void_p), ("relu", C.c_int),
                 ("R", C.c_void_p), ("ldr", C.c_int),
                 ("U", C.c_void_p), ("V", C.c_void_p), ("O", C.c_int), ("ldv", C.c_int),
-                ("colstats", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_size_t)]
+                ("colstats", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_size_t),
+                ("bnz", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_rstd", C.c_void_p), ("bnstats", C.c_void_p),
+                ("ldz", C.c_int)]
 
 
 class FcTensors(C.Structure):

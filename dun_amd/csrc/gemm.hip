@@ -45,6 +45,11 @@ struct GemmP {
     const float* V;
     int O, ldv;
     double* colstats;
+    const float* bnz;      // BatchNorm backward statistics of the block BELOW fused into this epilogue (dX GEMM): its
+    const float* bn_mean;  // ReLU output Z [M, ldz], batch mean / rstd [N]; bnstats float [2][gridM][N] receives the
+    const float* bn_rstd;  // per-row-tile column sums of C and C * (Z - mean) * rstd
+    float* bnstats;
+    int ldz;
     int gridM, gridN;
     int ksplit;   // > 1: blockIdx.y takes K range [y*K/ksplit, (y+1)*K/ksplit) and stores its raw sum to part[y]
     float* part;  // [ksplit][M][N]
@@ -125,11 +130,81 @@ __device__ __forceinline__ void read_frag(const float* lds, int row, int t, int 
     }
 }
 
-// ---- epilogue shared by both kernels.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-// FULL: the tile lies completely inside C (no bounds checks).
+// ---- element access of the 128x128 (64x64) output tile in the MFMA C/D layout -----------------------------------------
+// Element (mi, ni, r) of a lane: row = m0 + wr*WT + mi*32 + (r&3) + 8*(r>>2) + 4*h, col = n0 + wc*WT + ni*32 + li.
+// FULL tiles (the LDS-DMA kernels) go through buffer instructions: ONE per-lane byte offset per matrix
+// ((4h*ld + wc*WT + li)*4, + ni*128 as an immediate) and the row part ((m0 + wr*WT + mi*32 + (r&3) + 8(r>>2))*ld + n0)*4
+// as a SCALAR offset -- with flat addresses the 64 loads + 64 stores of an epilogue held a 64-bit address each and
+// the epilogue spilled.  Ragged tiles (register-staged kernels) use bounds-checked flat accesses.
 template <bool FULL, int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][MI], float* smem, int m0, int n0, int bm,
-                                              int tid, int wave, int wr, int wc, int li, int h) {
+struct TileIO {
+    static constexpr int WT = 32 * MI;
+    __amdgpu_buffer_rsrc_t rs;
+    const float* base;
+    int ld, voff, M, N, m0w, n0, colw, h;
+
+    __device__ __forceinline__ TileIO(const float* ptr, int ld_, const GemmP& p, int m0, int n0_, int wr, int wc, int li,
+                                      int h_) {
+        base = ptr; ld = ld_; M = p.M; N = p.N; h = h_;
+        m0w = m0 + wr * WT;        // wave-uniform on the FULL path (wr comes from a readfirstlane)
+        n0 = n0_;
+        colw = wc * WT + li;
+        if (FULL) {
+            rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)((((long long)p.M - 1) * ld + p.N) * 4),
+                                                   0x00020000);
+            voff = (4 * h * ld + colw) * 4;
+        }
+    }
+    __device__ __forceinline__ int rowu(int mi, int r) const { return m0w + mi * 32 + (r & 3) + 8 * (r >> 2); }
+    __device__ __forceinline__ bool inside(int mi, int ni, int r) const {
+        return FULL || (rowu(mi, r) + 4 * h < M && n0 + colw + ni * 32 < N);
+    }
+    __device__ __forceinline__ float load(int mi, int ni, int r) const {
+        if (FULL)
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + ni * 128,
+                                                                                  (rowu(mi, r) * ld + n0) * 4, 0));
+        return inside(mi, ni, r) ? base[(size_t)(rowu(mi, r) + 4 * h) * ld + n0 + colw + ni * 32] : 0.f;
+    }
+    __device__ __forceinline__ void store(int mi, int ni, int r, float v) const {
+        if (FULL)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff + ni * 128,
+                                                  (rowu(mi, r) * ld + n0) * 4, 0);
+        else if (inside(mi, ni, r))
+            const_cast<float*>(base)[(size_t)(rowu(mi, r) + 4 * h) * ld + n0 + colw + ni * 32] = v;
+    }
+};
+
+// C = R + A B with the accumulators STARTING from the R tile: its loads go out in front of the operand pipeline's
+// prologue and land under it, instead of a dependent HBM round trip in the epilogue behind an empty matrix pipe.
+template <bool FULL, int MI>
+__device__ __forceinline__ void seed_acc(const GemmP& p, f32x16 (&acc)[MI][MI], int m0, int n0, int wr, int wc, int li,
+                                         int h) {
+    if (p.rinit) {
+        const TileIO<FULL, MI> R(p.R, p.ldr, p, m0, n0, wr, wc, li, h);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < MI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = R.load(mi, ni, r);
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < MI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    }
+}
+
+// ---- epilogue shared by all kernels.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// FULL: the tile lies completely inside C (no bounds checks).
+// BNS: the launch takes the BatchNorm backward statistics (GemmP::bnz) -- then there is no bias / ReLU / residual /
+// forward statistics in the epilogue (host-checked), and the two forms are compiled apart so that neither carries the
+// other's registers.
+template <bool FULL, int MI, bool BNS>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, f32x16 (&acc)[MI][MI], float* smem, int m0, int n0,
+                                                   int bm, int tid, int wave, int wr, int wc, int li, int h) {
     constexpr int WT = 32 * MI;  // wave sub-tile edge
     // BatchNorm statistics are accumulated in fp64 from the first element on: sum z^2 - (sum z)^2/n in fp32
     // loses the variance of a nearly constant column (narrow inputs make many of those), and the reference's
@@ -140,27 +215,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][
     // Addends first, stores later.  R may BE C (the running gradient is updated in place), so the compiler cannot
     // move a residual load above an earlier store of this thread and would pay one HBM round trip per element; every
     // element is read and written by its own thread only, so gathering all of them up front is safe.
-    const bool has_r = p.R != nullptr, has_u1 = p.U != nullptr && p.O == 1;
-    float rr[MI][MI][16], uu[MI][16];
-    if (has_r) {
+    // The residual tile and the Z tile of the BatchNorm statistics share one register array: a launch has one or the
+    // other in its epilogue (the trunk's dX GEMM seeds its accumulators with the residual instead, `rinit`).
+    constexpr bool has_bn = BNS;
+    const bool has_r = !BNS && p.R != nullptr && !p.rinit, has_u1 = p.U != nullptr && p.O == 1;
+    const TileIO<FULL, MI> Cio(p.C, p.ldc, p, m0, n0, wr, wc, li, h);
+    float aux[MI][MI][16], uu[MI][16], sg[MI], sgx[MI];
 #pragma unroll
-        for (int ni = 0; ni < MI; ++ni) {
-            const int col = n0 + wc * WT + ni * 32 + li;
+    for (int ni = 0; ni < MI; ++ni) sg[ni] = sgx[ni] = 0.f;
+    if (has_r || has_bn) {
+        const TileIO<FULL, MI> Aio(has_bn ? p.bnz : p.R, has_bn ? p.ldz : p.ldr, p, m0, n0, wr, wc, li, h);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wr * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    rr[mi][ni][r] = (FULL || (row < p.M && col < p.N)) ? p.R[(size_t)row * p.ldr + col] : 0.f;
-                }
-        }
+            for (int ni = 0; ni < MI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) aux[mi][ni][r] = Aio.load(mi, ni, r);
     }
     if (has_u1) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = Cio.rowu(mi, r) + 4 * h;
                 uu[mi][r] = (FULL || row < p.M) ? p.U[row] : 0.f;
             }
     }
@@ -168,24 +245,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][
     for (int ni = 0; ni < MI; ++ni) {
         const int col = n0 + wc * WT + ni * 32 + li;
         const bool col_ok = FULL || col < p.N;
-        const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+        const float bv = (!BNS && p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
         const float v1 = (has_u1 && col_ok) ? p.V[col] : 0.f;
+        const float bmu = (has_bn && col_ok) ? p.bn_mean[col] : 0.f;
+        const float brs = (has_bn && col_ok) ? p.bn_rstd[col] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * WT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (FULL || (row < p.M && col_ok)) {
+                if (Cio.inside(mi, ni, r)) {
                     float v = acc[mi][ni][r] + bv;
-                    if (p.relu) v = v > 0.f ? v : 0.f;
-                    if (has_r) v += rr[mi][ni][r];
+                    if (!BNS && p.relu) v = v > 0.f ? v : 0.f;
+                    if (has_r) v += aux[mi][ni][r];
                     if (has_u1) {
                         v += uu[mi][r] * v1;
                     } else if (p.U != nullptr) {
+                        const int row = Cio.rowu(mi, r) + 4 * h;
                         for (int o = 0; o < p.O; ++o) v += p.U[(size_t)row * p.O + o] * p.V[(size_t)o * p.ldv + col];
                     }
-                    p.C[(size_t)row * p.ldc + col] = v;
-                    if (p.colstats != nullptr) {
+                    Cio.store(mi, ni, r, v);
+                    if (has_bn) {
+                        sg[ni] += v;
+                        sgx[ni] += v * ((aux[mi][ni][r] - bmu) * brs);
+                    }
+                    if (!BNS && p.colstats != nullptr) {
                         const double dv = (double)v;
                         s1[ni] += dv;
                         s2[ni] += dv * dv;
@@ -194,7 +277,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][
             }
         }
     }
-    if (p.colstats != nullptr) {
+    if (has_bn) {
+        // 32 rows per lane (fp32, as the column-owned reduction kernel sums 32 rows per thread), the two lane halves,
+        // then the two wave rows through LDS: one partial per 128-row (64-row) tile, fixed order
+        float* redf = smem;  // all waves are past the last barrier: LDS is free
+#pragma unroll
+        for (int ni = 0; ni < MI; ++ni) {
+            sg[ni] += __shfl_xor(sg[ni], 32, 64);
+            sgx[ni] += __shfl_xor(sgx[ni], 32, 64);
+            if (h == 0) {
+                redf[((wave * MI + ni) * 32 + li) * 2 + 0] = sg[ni];
+                redf[((wave * MI + ni) * 32 + li) * 2 + 1] = sgx[ni];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * WT) {
+            const int wc2 = tid / WT, ni2 = (tid / 32) % MI, l2 = tid & 31, col = n0 + tid;
+            if (FULL || col < p.N) {
+                const int w0 = wc2, w1 = 2 + wc2;  // wave rows 0 and 1 of this wave column
+                p.bnstats[(size_t)bm * p.N + col] =
+                    redf[((w0 * MI + ni2) * 32 + l2) * 2 + 0] + redf[((w1 * MI + ni2) * 32 + l2) * 2 + 0];
+                p.bnstats[(size_t)(p.gridM + bm) * p.N + col] =
+                    redf[((w0 * MI + ni2) * 32 + l2) * 2 + 1] + redf[((w1 * MI + ni2) * 32 + l2) * 2 + 1];
+            }
+        }
+    }
+    if (!BNS && p.colstats != nullptr) {
         double* red = reinterpret_cast<double*>(smem);  // all waves are past the last barrier: LDS is free
 #pragma unroll
         for (int ni = 0; ni < MI; ++ni) {
@@ -223,6 +331,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][
     }
 }
 
+template <bool FULL, int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][MI], float* smem, int m0, int n0, int bm,
+                                              int tid, int wave, int wr, int wc, int li, int h) {
+    if (p.bnz != nullptr)
+        gemm_epilogue_impl<FULL, MI, true>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    else
+        gemm_epilogue_impl<FULL, MI, false>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+}
+
 // MI = MFMA tiles per wave and dimension: 2 -> 128x128 workgroup tile, 1 -> 64x64 (problems too small to fill the
 // chip with 128-tiles: four times the workgroups, a quarter of the serial MFMA chain per workgroup)
 template <bool A_KC, bool B_KC, bool VEC, int MI>
@@ -247,12 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
 
     f32x16 acc[MI][MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < MI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    seed_acc<false, MI>(p, acc, m0, n0, wr, wc, li, h);  // (rinit is never set together with split-K)
 
     f32x4 ra[NR], rb[NR];
     // split-K: blockIdx.y owns [kb, ke), a whole number of K tiles (the last range may be short)
@@ -318,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         GemmP q = p;  // raw partial sum of this K range; splitk_sum_kernel adds the ranges in order
         q.C = p.part + (size_t)blockIdx.y * p.M * p.N;
         q.ldc = p.N;
-        q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr;
+        q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr; q.bnz = nullptr;
         gemm_epilogue<false, MI>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
     } else {
         gemm_epilogue<false, MI>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
@@ -387,12 +499,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmP p) {
     const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    seed_acc<true, 2>(p, acc, m0, n0, wr, wc, li, h);
 
     const int nk = p.K / BK;
     dma_tile<A_KC>(p.A, p.lda, m0, 0, smem, wave, lane);
@@ -540,28 +647,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
 
     f32x16 acc[2][2];
-    if (p.rinit) {
-        // C = R + A B with the accumulators STARTING from the R tile: its loads go out in front of the pipeline prologue
-        // and land under it, instead of a dependent HBM round trip in the epilogue with an empty matrix pipe
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wc * 64 + ni * 32 + li;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    acc[mi][ni][r] = p.R[(size_t)row * p.ldr + col];
-                }
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    }
+    seed_acc<true, 2>(p, acc, m0, n0, wr, wc, li, h);
 
     const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * (p.K / p.ksplit) : 0;
     const int nh = (p.ksplit > 1 ? p.K / p.ksplit : p.K) / HK;  // >= 2 (K range % 32 == 0)
@@ -582,7 +668,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     // pending at the loop entry shares lgkmcnt with the LDS reads, the counter is then no longer in-order for the
     // compiler, and it would wait for lgkmcnt(0) -- i.e. for the prefetch just issued -- at every MFMA group.
     asm volatile("" ::"s"(p.C), "s"(p.bias), "s"(p.R), "s"(p.U), "s"(p.V), "s"(p.colstats), "s"(p.M), "s"(p.N),
-                 "s"(p.ldc), "s"(p.ldr), "s"(p.O), "s"(p.ldv), "s"(p.relu), "s"(p.gridM), "s"(p.rinit));
+                 "s"(p.ldc), "s"(p.ldr), "s"(p.O), "s"(p.ldv), "s"(p.relu), "s"(p.gridM), "s"(p.rinit), "s"(p.bnz),
+                 "s"(p.bn_mean), "s"(p.bn_rstd), "s"(p.bnstats), "s"(p.ldz));
 
     float fa[2][2][4], fb[2][2][4];
 #pragma unroll
@@ -641,11 +728,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
         GemmP q = p;  // raw partial sum of this K range; splitk_sum_kernel adds the ranges in order
         q.C = p.part + (size_t)blockIdx.y * p.M * p.N;
         q.ldc = p.N;
-        q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr;
-        gemm_epilogue<true, 2>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
-    } else if (p.rinit) {
-        GemmP q = p;
-        q.R = nullptr;  // already inside the accumulators
+        q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr; q.bnz = nullptr;
         gemm_epilogue<true, 2>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
     } else {
         gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
@@ -738,6 +821,9 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     p.R = d->R; p.ldr = d->ldr;
     p.U = d->U; p.V = d->V; p.O = d->O; p.ldv = d->ldv;
     p.colstats = d->colstats;
+    p.bnz = d->bnz; p.bn_mean = d->bn_mean; p.bn_rstd = d->bn_rstd; p.bnstats = d->bnstats; p.ldz = d->ldz;
+    DUN_REQUIRE(d->bnz == nullptr || (d->bn_mean && d->bn_rstd && d->bnstats && d->ldz >= d->N),
+                "dun_gemm_f32: bnz needs bn_mean, bn_rstd, bnstats and ldz >= N");
     p.gm = 1;
     p.rinit = 0;
     const bool small = small_problem(d->M, d->N);
@@ -756,7 +842,7 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     p.ksplit = 1;
     p.part = nullptr;
     const long long tiles = (long long)p.gridM * p.gridN;
-    const bool plain = !d->bias && !d->relu && !d->R && !d->U && !d->colstats;
+    const bool plain = !d->bias && !d->relu && !d->R && !d->U && !d->colstats && !d->bnz;
     const bool fits32 = (long long)(d->a_kcontig ? d->M : d->K) * d->lda * 4 < (1ll << 31) &&
                         (long long)(d->b_kcontig ? d->N : d->K) * d->ldb * 4 < (1ll << 31);
     if (dma && plain && fits32 && !g_dma_two_buffer && !g_no_splitk && tiles < 512 && d->K % 64 == 0 && d->K >= 2048 &&
@@ -779,15 +865,20 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
             p.part = d->splitk_ws;
         }
     }
-    if (dma && p.ksplit == 1) {
+    {
         // A/B hooks.  DUN_GEMM_GM=g: tiles ordered in groups of g row panels (measured at the wide configuration's shapes,
         // g = 4, 8, 16: no change in any of the three GEMMs -- the kernels are not bound by L2 misses; default 1).
         // DUN_GEMM_RINIT=0: residual added in the epilogue instead of seeding the accumulators (dX 3.94 -> 3.90 ms with
         // the seeding, within 10 us of the epilogue-free kernel).
         static const int env_gm = getenv("DUN_GEMM_GM") ? atoi(getenv("DUN_GEMM_GM")) : 1;
         static const int env_rinit = getenv("DUN_GEMM_RINIT") ? atoi(getenv("DUN_GEMM_RINIT")) : 1;
-        p.gm = env_gm > 1 ? env_gm : 1;
-        p.rinit = (env_rinit && d->R && !d->bias && !d->relu) ? 1 : 0;
+        p.gm = (dma && env_gm > 1) ? env_gm : 1;
+        const bool can_seed = d->R && !d->bias && !d->relu && p.ksplit == 1;
+        if (d->bnz && (d->bias || d->relu || d->colstats || (d->R && !can_seed))) {
+            set_error("dun_gemm_f32: bnz together with bias / ReLU / colstats is not implemented");
+            return DUN_ERR_UNSUPPORTED;
+        }
+        p.rinit = (can_seed && (env_rinit || d->bnz)) ? 1 : 0;  // (the statistics epilogue shares the residual's registers)
     }
     if (d->a_kcontig) {
         if (d->b_kcontig) return launch_gemm<true, true>(p, vec, dma, small, s);

@@ -10,6 +10,7 @@
 //             head's rank-O term dact_i w_out folded into that epilogue, so no dH tensor is ever written).
 // Hidden states of all depths live in one [D,B,W] buffer: the head reads it as one batched contraction.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -723,8 +724,22 @@ static int bwd_begin(const dun_fc_ctx* c, hipStream_t s) {
     return DUN_OK;
 }
 
+// The column sums sum_b g and sum_b g*xhat of block i are taken in the epilogue of the dX GEMM of block i+1, while the
+// tile of g it has just computed is in registers (one read of Z_i instead of a pass over g and Z_i): every block but the
+// deepest, whose incoming gradient does not come out of a GEMM.  DUN_BWD_STATS_IN_GEMM=0 keeps the separate pass (A/B).
+static const bool g_stats_in_gemm = !(getenv("DUN_BWD_STATS_IN_GEMM") && getenv("DUN_BWD_STATS_IN_GEMM")[0] == '0');
+static inline bool stats_from_gemm(const dun_fc_ctx* c, int i) { return g_stats_in_gemm && i < c->L - 1; }
+
 static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
-    const int W = c->W, B = c->B, P = num_slabs(B);
+    const int W = c->W, B = c->B;
+    if (stats_from_gemm(c, i)) {
+        // per-row-tile partials [2][T][W] left in the workspace by bwd_block_dx_gemm(i+1)
+        hipLaunchKernelGGL(reduce_cols_kernel<float>, dim3(ceil_div(W, RCX), 2), dim3(256), 0, s, c->ws,
+                           gemm_colstat_tiles(B, W), W, c->bn_sums, c->g.beta + (size_t)i * W, c->g.gamma + (size_t)i * W);
+        DUN_LAUNCH_CHECK();
+        return DUN_OK;
+    }
+    const int P = num_slabs(B);
     const int nt = stream_nt((size_t)B * W * 4) ? 1 : 0;
     const float* Z = Zd(c, i);
     const float* mean = c->bn_mean + (size_t)i * W;
@@ -796,6 +811,12 @@ static int bwd_block_dx_gemm(const dun_fc_ctx* c, int i, hipStream_t s) {
     g.M = c->B; g.N = W; g.K = W;
     if (c->residual) { g.R = c->G; g.ldr = W; }
     g.U = c->dact + (size_t)i * c->B * c->O; g.V = c->p.w_out; g.O = c->O; g.ldv = W;
+    if (i >= 1 && stats_from_gemm(c, i - 1)) {  // the BatchNorm backward of block i-1 starts from this g
+        g.bnz = Zd(c, i - 1); g.ldz = W;
+        g.bn_mean = c->bn_mean + (size_t)(i - 1) * W;
+        g.bn_rstd = c->bn_rstd + (size_t)(i - 1) * W;
+        g.bnstats = c->ws;  // float [2][T][W]: fits the forward statistics' fp64 [2][T][W] region
+    }
     return gemm_f32(&g, s);
 }
 

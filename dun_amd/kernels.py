@@ -295,7 +295,9 @@ class HipBackend(object):
 
     # ---- raw GEMM (tests / benchmarks) ----------------------------------------------------------------
     def gemm(self, A, B, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, relu=False, R=None, U=None, V=None,
-             colstats=False, out=None, splitk_ws=None):
+             colstats=False, out=None, splitk_ws=None, bn=None):
+        """bn = (Z [M,N], mean [N], rstd [N]): also return the per-row-tile column sums of C and C*(Z-mean)*rstd
+        (float [2][T][N], the BatchNorm backward statistics the trunk's dX GEMM emits for the block below)."""
         dev = A.device
         Cm = out if out is not None else torch.empty(M, N, device=dev, dtype=torch.float32)
         d = L.GemmDesc()
@@ -315,7 +317,13 @@ class HipBackend(object):
             d.colstats = L.ptr(stats)
         if splitk_ws is not None:
             d.splitk_ws, d.splitk_ws_floats = L.f32(splitk_ws), splitk_ws.numel()
+        bnstats = None
+        if bn is not None:
+            bnstats = torch.empty(2, L.lib().dun_gemm_colstat_tiles(M, N), N, device=dev, dtype=torch.float32)
+            d.bnz, d.bn_mean, d.bn_rstd, d.bnstats, d.ldz = L.f32(bn[0]), L.f32(bn[1]), L.f32(bn[2]), L.f32(bnstats), N
         L.check(L.lib().dun_gemm_f32(C.byref(d), L.stream_ptr(dev)), "dun_gemm_f32")
+        if bn is not None:
+            return Cm, bnstats
         return (Cm, stats) if colstats else Cm
 
 

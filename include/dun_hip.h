@@ -163,6 +163,16 @@ typedef struct dun_gemm_desc {
     double* colstats;  /* NULL, or fp64 [2][T][N], T = dun_gemm_colstat_tiles(M, N): per row-tile column sums of C, C^2 */
     float* splitk_ws;  /* NULL, or scratch of splitk_ws_floats floats: lets an epilogue-free problem with few output */
     size_t splitk_ws_floats; /* tiles and a long K (dW = dU^T H) split K over two workgroups per tile; >= 2*M*N to be used */
+    /* NULL, or the BatchNorm backward column statistics of the NEXT layer down, taken while the output tile is in
+     * registers (the trunk's dX GEMM writes the running gradient g; the BatchNorm backward of the block below starts
+     * with sum_b g and sum_b g*xhat): bnz = that block's ReLU output Z [M, ldz], bn_mean / bn_rstd [N] its batch
+     * statistics; bnstats float [2][T][N], T = dun_gemm_colstat_tiles(M, N): per row-tile column sums of C and of
+     * C * (Z - mean) * rstd. */
+    const float* bnz;
+    const float* bn_mean;
+    const float* bn_rstd;
+    float* bnstats;
+    int ldz;
 } dun_gemm_desc;
 int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream);
 /* Row tiles the kernel uses for an M x N problem (128-row tiles; 64-row tiles when the problem is too small to fill

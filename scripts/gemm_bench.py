@@ -29,6 +29,9 @@ for rep in range(2):
     print("fwd  %.3f ms  %.1f TF" % (ms, fl / ms / 1e9))
     ms = timed(lambda: be.gemm(Z, w, B, W, W, a_kcontig=True, b_kcontig=False, R=out, U=u1, V=v1, out=out), 10)
     print("dX   %.3f ms  %.1f TF  (in-place residual + rank-1 head term, as in the step)" % (ms, fl / ms / 1e9))
+    mean, rstd = torch.randn(W, device="cuda", generator=g), torch.rand(W, device="cuda", generator=g) + 0.5
+    ms = timed(lambda: be.gemm(Z, w, B, W, W, a_kcontig=True, b_kcontig=False, R=out, U=u1, V=v1, out=out, bn=(H, mean, rstd)), 10)
+    print("dX   %.3f ms  %.1f TF  (same + BatchNorm backward statistics of the block below in the epilogue)" % (ms, fl / ms / 1e9))
     wT = w.t().contiguous()
     ms = timed(lambda: be.gemm(Z, wT, B, W, W, a_kcontig=True, b_kcontig=True, R=out, U=u1, V=v1, out=out), 10)
     print("dX   %.3f ms  %.1f TF  (same, against a transposed copy of W: both operands K-contiguous)" % (ms, fl / ms / 1e9))

@@ -101,6 +101,26 @@ def test_gemm_epilogues(be, M, N, K, O):
     assert (out.cpu().double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 100, 100), (2048, 1024, 64), (2050, 1030, 70), (4096, 512, 256)])
+def test_gemm_batchnorm_backward_statistics_epilogue(be, M, N, K):
+    """dX form with the next block's BatchNorm backward column sums taken in the epilogue: C = R + A B + u v^T in place,
+    and per row tile sum_rows C, sum_rows C * (Z - mean) * rstd."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, Bm = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    R, Z = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g).relu()
+    U, V = torch.randn(M, 1, generator=g), torch.randn(1, N, generator=g)
+    mean, rstd = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    Rd = dev(R.clone())
+    out, st = be.gemm(dev(A), dev(Bm), M, N, K, a_kcontig=True, b_kcontig=False, R=Rd, U=dev(U), V=dev(V), out=Rd,
+                      bn=(dev(Z), dev(mean), dev(rstd)))
+    ref = A.double() @ Bm.double() + R.double() + U.double() @ V.double()
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    xh = (Z.double() - mean.double()) * rstd.double()
+    s = st.cpu().double().sum(dim=1)
+    assert rel_err(s[0], ref.sum(0)) < 2e-5
+    assert rel_err(s[1], (ref * xh).sum(0)) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------------
 # probability module
 # ------------------------------------------------------------------------------------------------------
