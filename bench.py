@@ -219,10 +219,15 @@ def kernel_rooflines(net, B_local, reps):
     u1 = torch.randn(B_local, 1, device=Z0.device) * 1e-3
     v1 = model.stacked["w_out"]
     # dX on the operands the step left behind: A = dU of the last block processed, running gradient updated in place
+    # and in the form the step launches: against the transposed copy of the block weights (both operands K-contiguous),
+    # residual seeding the accumulators, BatchNorm backward column statistics of the block below in the epilogue
     scratch.copy_(buf.G)
-    ms = timed(lambda: be.gemm(buf.dU, w0, B_local, W, W, a_kcontig=True, b_kcontig=False, R=scratch, U=u1, V=v1,
-                               out=scratch), reps)
-    out["gemm_dx"] = dict(kernel=gemm_kernel_name(B_local, W, W, 1, 0) + " (dX = dU W + g + dact w_out, in place)", ms=ms, tflops=flops / ms / 1e9)
+    w0t = w0.t().contiguous()
+    bn = (Z0, buf.bn_mean[0], buf.bn_rstd[0])
+    ms = timed(lambda: be.gemm(buf.dU, w0t, B_local, W, W, a_kcontig=True, b_kcontig=True, R=scratch, U=u1, V=v1,
+                               out=scratch, bn=bn), reps)
+    out["gemm_dx"] = dict(kernel=gemm_kernel_name(B_local, W, W, 1, 1) + " (dX = dU W + g + dact w_out in place, + BN-backward "
+                                 "column sums of the block below)", ms=ms, tflops=flops / ms / 1e9)
     gw = model.stacked_grad["w"][0]
     skws = torch.empty(2 * W * W, device=Z0.device)
     ms = timed(lambda: be.gemm(buf.dU, H0, W, W, B_local, a_kcontig=False, b_kcontig=False, out=gw, splitk_ws=skws),

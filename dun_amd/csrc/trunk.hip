@@ -460,6 +460,26 @@ __global__ __launch_bounds__(256) void rank_init_kernel(float* __restrict__ G, c
     }
 }
 
+// out[l][c][r] = in[l][r][c] for L square W x W matrices (W % 64 == 0): 64x64 tiles through LDS (+1 padding)
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int W) {
+    __shared__ float tile[64][65];
+    const size_t mat = (size_t)blockIdx.z * W * W;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = ty * 16 + j;
+        tile[r][tx] = in[mat + (size_t)(r0 + r) * W + c0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = ty * 16 + j;
+        out[mat + (size_t)(c0 + c) * W + r0 + tx] = tile[tx][c];
+    }
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, size_t n, float lr, float momentum,
                                                   float wd) {
@@ -711,9 +731,13 @@ static int check_bwd(const dun_fc_ctx* c, const char* who) {
     return DUN_OK;
 }
 
+static int transpose_block_weights(const dun_fc_ctx* c, hipStream_t s);
+
 static int bwd_begin(const dun_fc_ctx* c, hipStream_t s) {
     const int rows = (c->depth + 1) * c->B;
-    int rc = head_backward(c->H, c->p.w_out, c->dact, rows, c->W, c->O, c->g.w_out, c->g.b_out, nullptr, c->ws,
+    int rc = transpose_block_weights(c, s);
+    if (rc) return rc;
+    rc = head_backward(c->H, c->p.w_out, c->dact, rows, c->W, c->O, c->g.w_out, c->g.b_out, nullptr, c->ws,
                            c->ws_floats, s);
     if (rc) return rc;
     const size_t n = (size_t)c->B * c->W;
@@ -800,6 +824,25 @@ static int bwd_block_dw(const dun_fc_ctx* c, int i, hipStream_t s) {
     return gemm_f32(&g, s);
 }
 
+// Transposed copies of the block weights for the dX GEMMs (behind the tiled path's workspace).  g = dU W_i contracts over
+// the OUTPUT index of W_i[n_out][k_in], so W_i as stored is the N-contiguous operand; with both operands K-contiguous
+// the same kernel runs at the forward GEMM's rate (measured box to box 25 ... 150 us per launch faster at the wide
+// configuration's shape), for one 2 x L x W^2 x 4-byte transposition per backward (0.3 ms at 50 x 2048^2) and one more
+// copy of the block weights in the workspace.  DUN_DX_TRANSPOSED=0 keeps the weights as stored (A/B).
+static const bool g_dx_transposed = !(getenv("DUN_DX_TRANSPOSED") && getenv("DUN_DX_TRANSPOSED")[0] == '0');
+static inline bool dx_transposed(int B, int W, int L) {
+    return g_dx_transposed && L > 0 && W % 128 == 0 && B % 128 == 0 && (long long)ceil_div(B, 128) * (W / 128) >= 128;
+}
+static size_t base_workspace_floats(int B, int W, int O, int L);
+static inline float* wT_base(const dun_fc_ctx* c) { return c->ws + base_workspace_floats(c->B, c->W, c->O, c->L); }
+
+static int transpose_block_weights(const dun_fc_ctx* c, hipStream_t s) {
+    if (!dx_transposed(c->B, c->W, c->L)) return DUN_OK;
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(c->W / 64, c->W / 64, c->L), dim3(256), 0, s, c->p.w, wT_base(c), c->W);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
 // g <- [g +] dU W_i + dact_i w_out   (in place: every element is read and written by its own thread)
 static int bwd_block_dx_gemm(const dun_fc_ctx* c, int i, hipStream_t s) {
     const int W = c->W;
@@ -807,6 +850,7 @@ static int bwd_block_dx_gemm(const dun_fc_ctx* c, int i, hipStream_t s) {
     memset(&g, 0, sizeof(g));
     g.A = c->dU; g.lda = W; g.a_kcontig = 1;
     g.B = c->p.w + (size_t)i * W * W; g.ldb = W; g.b_kcontig = 0;
+    if (dx_transposed(c->B, W, c->L)) { g.B = wT_base(c) + (size_t)i * W * W; g.b_kcontig = 1; }
     g.C = c->G; g.ldc = W;
     g.M = c->B; g.N = W; g.K = W;
     if (c->residual) { g.R = c->G; g.ldr = W; }
@@ -860,7 +904,9 @@ static int bwd_end(const dun_fc_ctx* c, hipStream_t s) {
 
 using namespace dun;
 
-// workspace of the tiled path, rounded to 256 bytes; the small-net path keeps its second dU buffer behind it
+// workspace of the tiled path, rounded to 256 bytes; behind it the small-net path keeps its second dU buffer, or the
+// tiled path the transposed block weights of its dX GEMMs
+namespace dun {
 static size_t base_workspace_floats(int B, int W, int O, int L) {
     const size_t P = (size_t)ceil_div(B, 64);  // upper bound of the GEMM's row tiles (and of num_slabs(B))
     const size_t cols = 4 * P * (size_t)W;  // fp64 [2][P][W] forward statistics partials
@@ -870,6 +916,7 @@ static size_t base_workspace_floats(int B, int W, int O, int L) {
     if (sk > m) m = sk;
     return (m + 64 + 63) / 64 * 64;
 }
+}  // namespace dun
 
 extern "C" int dun_fc_obj_num_partials(int B, int O) { return (B > 0 && O == 1) ? obj_nparts(B) : 0; }
 
@@ -877,7 +924,8 @@ extern "C" int dun_fc_head_is_fused(const dun_fc_ctx* c) { return (c != nullptr 
 
 extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
     (void)din;
-    return base_workspace_floats(B, W, O, L) + sn_extra_ws_floats(B, W, L);
+    const size_t wT = dx_transposed(B, W, L) ? (size_t)L * W * W : 0;
+    return base_workspace_floats(B, W, O, L) + sn_extra_ws_floats(B, W, L) + wT;
 }
 
 #define STREAM static_cast<hipStream_t>(stream)
