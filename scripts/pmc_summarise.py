@@ -37,7 +37,7 @@ def load(dirname):
     return rows
 
 
-def kernel_stats(dirname, out):
+def kernel_stats(dirname, out, split_by_grid=True):
     """rocprofv3 --kernel-trace --stats -> per-kernel calls / total / average / min / max / percentage as CSV."""
     import sqlite3
     agg = collections.defaultdict(list)
@@ -48,17 +48,34 @@ def kernel_stats(dirname, out):
     for path in glob.glob(os.path.join(dirname, "**", "*kernel_trace.csv"), recursive=True):
         with open(path, newline="") as f:
             for r in csv.DictReader(f):
-                agg[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                # one row per (kernel, launch geometry): a kernel launched on several shapes (the trunk GEMM on the block
+                # shape and on the input layer's) gets one line per shape, so averages are per shape
+                name = r["Kernel_Name"]
+                if split_by_grid:
+                    name += "  [grid %sx%sx%s]" % (int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1),
+                                                   int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1),
+                                                   int(r["Grid_Size_Z"]) // max(int(r["Workgroup_Size_Z"]), 1))
+                agg[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     total = float(sum(sum(v) for v in agg.values())) or 1.0
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        # MedianNs / MainShapeAverageNs: a kernel whose launches share a grid but not a problem size (the trunk's forward
+        # GEMM runs the K = 64 input layer on the same 8192-tile grid as the K = 2048 blocks) is summarised by its median
+        # and by the average over the launches within a factor two of the median, i.e. over its main shape only
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "MedianNs",
+                    "MainShapeCalls", "MainShapeAverageNs"])
         for k in sorted(agg, key=lambda k: -sum(agg[k])):
             v = agg[k]
-            w.writerow([k, len(v), sum(v), "%.1f" % (sum(v) / len(v)), "%.3f" % (100.0 * sum(v) / total), min(v), max(v)])
+            m = statistics.median(v)
+            main = [t for t in v if 0.5 * m <= t <= 2.0 * m]
+            w.writerow([k, len(v), sum(v), "%.1f" % (sum(v) / len(v)), "%.3f" % (100.0 * sum(v) / total), min(v), max(v),
+                        "%.1f" % m, len(main), "%.1f" % (sum(main) / len(main))])
     for k in sorted(agg, key=lambda k: -sum(agg[k]))[:8]:
-        print("%-80s n=%4d avg %10.1f us  %5.1f%%" % (k[:80], len(agg[k]), sum(agg[k]) / len(agg[k]) / 1e3,
-                                                      100.0 * sum(agg[k]) / total))
+        m = statistics.median(agg[k])
+        main = [t for t in agg[k] if 0.5 * m <= t <= 2.0 * m]
+        print("%-80s n=%4d avg %10.1f us  main shape n=%4d avg %10.1f us  %5.1f%%" %
+              (k[:80], len(agg[k]), sum(agg[k]) / len(agg[k]) / 1e3, len(main), sum(main) / len(main) / 1e3,
+               100.0 * sum(agg[k]) / total))
 
 
 def med(d):
@@ -68,12 +85,14 @@ def med(d):
 # bench.py's roofline names -> substring of the kernel symbol that runs it in the training step
 ROLE = {
     "gemm_fwd": "gemm_f32_dma4_kernel<true, true>",
-    "gemm_dx": "gemm_f32_dma4_kernel<true, false>",
+    "gemm_dx": "gemm_f32_dma4_kernel<true, false>",   # (only with DUN_DX_TRANSPOSED=0: dX runs on <true, true> otherwise)
     "gemm_dw": "gemm_f32_dma4_kernel<false, false>",
     "head_fwd": "head_fwd_kernel",
     "head_bwd": "head_bwd_kernel",
     "elbo": "ll_gauss_kernel",
     "bn_apply": "bn_apply_kernel",
+    "bn_apply_head": "bn_apply_head_kernel",
+    "head_obj": "head_obj_kernel",
     "bn_bwd_apply": "bn_bwd_apply_kernel",
     "bn_bwd_reduce": "bn_bwd_reduce_kernel",
 }
