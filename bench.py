@@ -199,7 +199,7 @@ def small_net_rooflines(net, B_local, reps):
     }
 
 
-def kernel_rooflines(net, B_local, reps):
+def kernel_rooflines(net, B_local, reps, y=None):
     """Live per-kernel timings on the buffers of the training step (same shapes, same data)."""
     from dun_amd import kernels
     be = kernels.backend()
@@ -240,6 +240,20 @@ def kernel_rooflines(net, B_local, reps):
     dact = torch.randn(D * B_local, 1, device=Hall.device)
     ms = timed(lambda: be.head_backward(Hall, model.stacked["w_out"], dact, need_dH=False), reps)
     out["head_bwd"] = dict(ms=ms, gbs=4.0 * D * B_local * W / ms / 1e6)
+    # What the step really runs for the head and the objective: BatchNorm apply + residual + head row-dot + Gaussian
+    # likelihood terms (act, dact, per-depth partial sums) in ONE row-owned pass over a [B,W] plane (dun_fc_block_norm:
+    # a W-element statistics kernel + bn_apply_head_kernel).  Algorithmic bytes: Z and H_in read, H_out written
+    # (12*B*W) + y read, act and dact written (12*B).
+    if y is not None and buf.head_fused:
+        rm, rv = model.running_mean.clone(), model.running_var.clone()
+        spec = net.prob_model.head_objective(y, net.f_neg_loglike, B_local)
+        buf.new_act()
+        buf.set_objective(spec)
+        ms = timed(lambda: be.fc_block_norm(buf, 0, float(B_local)), reps)
+        buf.set_objective(None)
+        model.running_mean.copy_(rm)
+        model.running_var.copy_(rv)
+        out["head_elbo_fused"] = dict(ms=ms, gbs=(12.0 * B_local * W + 12.0 * B_local) / ms / 1e6)
     # fused ELBO pass (Gaussian likelihood + per-depth reduction + dact in one sweep) on act_vec [D,B]:
     # 8*D*B + 4*B algorithmic bytes.  Timed as the bare C-ABI call on preallocated buffers.
     from dun_amd import _lib as L
@@ -591,7 +605,7 @@ def run_rank(args):
             result["data"] = "synthetic, tiny; CPU rehearsal of the launch path"
             result["dtype"] = "f32 (torch CPU stand-in)"
     if rank == 0 and not args.no_kernel_rooflines:
-        kr = kernel_rooflines(net, B_local, reps=5 if args.workload == "c3_wide" else 20)
+        kr = kernel_rooflines(net, B_local, reps=5 if args.workload == "c3_wide" else 20, y=y)
         # dominant kernel of the step: the trunk GEMM (3*L launches per step); quote the forward instantiation
         dom = kr["gemm_fwd"]
         small = small_net_path(B_local, W)
