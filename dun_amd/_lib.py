@@ -20,7 +20,7 @@ EXPORTS = [
     "dun_depth_finalize", "dun_depth_finalize_partials", "dun_elbo_gauss_workspace_doubles", "dun_elbo_gauss",
     "dun_static_init", "dun_elbo_gauss_static_max_doubles", "dun_elbo_gauss_static", "dun_predict_gauss", "dun_predict_softmax", "dun_predict_num_partials", "dun_gemm_f32", "dun_gemm_colstat_tiles",
     "dun_fc_workspace_floats", "dun_fc_obj_num_partials", "dun_fc_head_is_fused", "dun_fc_forward", "dun_fc_backward", "dun_fc_input_layer", "dun_fc_block_linear",
-    "dun_fc_block_norm", "dun_fc_head", "dun_fc_head_depth", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply", "dun_fc_bwd_block_dx", "dun_fc_bwd_block_dw",
+    "dun_fc_block_norm", "dun_fc_block_apply", "dun_fc_head", "dun_fc_head_depth", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply", "dun_fc_bwd_block_dx", "dun_fc_bwd_block_dw",
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
 ]
 
@@ -93,6 +93,7 @@ def _declare(lib):
         "dun_fc_input_layer": (i, [C.POINTER(FcCtx), vp]),
         "dun_fc_block_linear": (i, [C.POINTER(FcCtx), i, vp]),
         "dun_fc_block_norm": (i, [C.POINTER(FcCtx), i, d, vp]),
+        "dun_fc_block_apply": (i, [C.POINTER(FcCtx), i, vp]),
         "dun_fc_head": (i, [C.POINTER(FcCtx), vp]),
         "dun_fc_head_depth": (i, [C.POINTER(FcCtx), i, vp]),
         "dun_fc_bwd_begin": (i, [C.POINTER(FcCtx), vp]),

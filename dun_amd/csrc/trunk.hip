@@ -644,12 +644,16 @@ static int block_linear(const dun_fc_ctx* c, int i, hipStream_t s, bool reduce_s
 }
 
 // from_partials: the GEMM's per-tile statistics are still unreduced in the workspace (single-device forward)
-static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s, bool from_partials = false) {
+// apply_only: the statistics of block i are already in bn_mean / bn_rstd (dun_fc_block_apply)
+static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream_t s, bool from_partials = false,
+                      bool apply_only = false) {
     const int W = c->W, B = c->B;
     const float* mean;
     const float* stat;
     int is_var;
-    if (c->train) {
+    if (c->train && apply_only) {
+        mean = c->bn_mean + (size_t)i * W; stat = c->bn_rstd + (size_t)i * W; is_var = 0;
+    } else if (c->train) {
         DUN_REQUIRE(global_batch > 1.0, "dun_fc_block_norm: BatchNorm in train mode needs more than 1 row (got %g)",
                     global_batch);
         float* m = c->bn_mean + (size_t)i * W;
@@ -941,6 +945,10 @@ extern "C" int dun_fc_block_linear(const dun_fc_ctx* c, int i, dun_stream_t stre
 extern "C" int dun_fc_block_norm(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream) {
     int rc = check_block(c, i, "dun_fc_block_norm");
     return rc ? rc : block_norm(c, i, global_batch, STREAM);
+}
+extern "C" int dun_fc_block_apply(const dun_fc_ctx* c, int i, dun_stream_t stream) {
+    int rc = check_block(c, i, "dun_fc_block_apply");
+    return rc ? rc : block_norm(c, i, (double)c->B, STREAM, false, /*apply_only=*/true);
 }
 extern "C" int dun_fc_head(const dun_fc_ctx* c, dun_stream_t stream) {
     int rc = check_ctx(c, "dun_fc_head");

@@ -241,6 +241,9 @@ class HipBackend(object):
     def fc_block_norm(self, buf, i, global_batch):
         self._fc("dun_fc_block_norm", buf, i, float(global_batch))
 
+    def fc_block_apply(self, buf, i):
+        self._fc("dun_fc_block_apply", buf, i)
+
     def fc_head(self, buf):
         self._fc("dun_fc_head", buf)
 

@@ -258,6 +258,10 @@ int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream); /* whole net, nee
 int dun_fc_input_layer(const dun_fc_ctx* c, dun_stream_t stream);
 int dun_fc_block_linear(const dun_fc_ctx* c, int i, dun_stream_t stream);
 int dun_fc_block_norm(const dun_fc_ctx* c, int i, double global_batch, dun_stream_t stream);
+/* The second half of dun_fc_block_norm alone: normalise + affine + residual (+ head and likelihood terms where
+ * dun_fc_head_is_fused) with the statistics block_norm left in bn_mean / bn_rstd (eval mode: running statistics).
+ * For callers that time or re-run the streaming pass by itself. */
+int dun_fc_block_apply(const dun_fc_ctx* c, int i, dun_stream_t stream);
 int dun_fc_head(const dun_fc_ctx* c, dun_stream_t stream);
 int dun_fc_head_depth(const dun_fc_ctx* c, int d, dun_stream_t stream);
 int dun_fc_bwd_begin(const dun_fc_ctx* c, dun_stream_t stream);
