@@ -34,6 +34,7 @@ class FcBuffers(object):
         self.x = None
         self.dact = None
         self._obj = None
+        self.generation = 0  # bumped by every forward that writes these buffers
         c = L.FcCtx()
         c.B, c.din, c.W, c.O, c.L = B, din, W, O, Lyr
         c.residual, c.train, c.depth = int(model.residual), int(train), depth

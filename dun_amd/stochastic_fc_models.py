@@ -27,7 +27,7 @@ class _FcForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, depth, objective, *params):
         buf = model._run_forward(x, depth, True, objective)
-        ctx.model, ctx.buf = model, buf
+        ctx.model, ctx.buf, ctx.generation = model, buf, buf.generation
         # The returned tensor becomes this node's output (grad_fn -> node -> parameters -> model).  Left in the buffer
         # object it would close model -> buffers -> act -> node -> model through the C++ autograd graph, which
         # Python's collector cannot see: a dropped model kept its activation buffers (55 GB at C3) allocated.
@@ -40,6 +40,12 @@ class _FcForward(torch.autograd.Function):
         if buf is None:
             raise RuntimeError("the trunk's backward ran already (its buffers are reused by the next forward)")
         ctx.model = ctx.buf = None  # a kept act_vec does not pin the buffers
+        if buf.generation != ctx.generation:
+            # H / Z / BatchNorm statistics live in ONE buffer set per (batch, depth, mode): a later train-mode forward
+            # of the same batch size (also under no_grad, e.g. a sweep with train_bn=True) has overwritten what this
+            # backward needs.  Gradients are also written, not accumulated (no micro-batch accumulation).
+            raise RuntimeError("the trunk's activation buffers were reused by a later train-mode forward of the same batch "
+                               "size before this backward ran; run backward before the next forward")
         model._run_backward(buf, dact)
         return (None, None, None, None) + (None,) * len(model._param_list)
 
@@ -216,6 +222,7 @@ class arq_uncert_fc_resnet(nn.Module):
         be = kernels.backend()
         x = x.detach().to(torch.float32).contiguous()
         buf = self._get_buffers(x.shape[0], depth, train)
+        buf.generation += 1
         buf.new_act()
         buf.set_input(x)
         buf.set_objective(objective if self.output_dim == 1 else None)

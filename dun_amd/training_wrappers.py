@@ -172,22 +172,35 @@ class DUN(BaseNet):
                 None if q is None else bool(q.requires_grad), model.flat_params.data_ptr(), id(self.optimizer),
                 float(self.N_train), type(self).__name__)
 
+    graph_cache_size = 4  # captured steps kept per wrapper (full batch, ragged tail batch, a second loader, ...)
+
     def _fit_maybe_graphed(self, x, y, step_fn):
-        """step_fn(x, y) -> (metrics tensor, divisor) enqueues one optimisation step without host syncs."""
+        """step_fn(x, y) -> (metrics tensor, divisor) enqueues one optimisation step without host syncs.
+
+        One captured graph per configuration key, a few kept at a time: a loader whose last batch is ragged alternates
+        between two keys every epoch and replays both instead of re-capturing.  ``prob_model.current_posterior`` after
+        a replayed step is that graph's static output tensor, overwritten by its next replay (the reference hands out
+        a fresh tensor per step): callers that keep it across steps clone it."""
         key = self._graph_key(x, y)
-        st = self.__dict__.get("_graph_state")
         if key is None:
             return self._metrics_host(*step_fn(x, y))
-        if st is not None and st["key"] == key and st["graph"] is not None:
+        states = self.__dict__.setdefault("_graph_states", {})
+        st = states.get(key)
+        if st is None:
+            # first step with this configuration runs eagerly (builds buffers / optimizer state, loads kernels)
+            while len(states) >= self.graph_cache_size:
+                states.pop(next(iter(states)))  # oldest first
+            st = states[key] = dict(key=key, graph=None)
+            self._graph_state = st
+            return self._metrics_host(*step_fn(x, y))
+        states[key] = states.pop(key)  # most recently used last
+        self._graph_state = st
+        if st["graph"] is not None:
             st["x"].copy_(x, non_blocking=True)
             st["y"].copy_(y, non_blocking=True)
             st["graph"].replay()
             self.prob_model.current_posterior = st["posterior"]
             return self._metrics_host(st["m"], st["n"])
-        if st is None or st["key"] != key:
-            # first step with this configuration runs eagerly (builds buffers / optimizer state, loads kernels)
-            self._graph_state = dict(key=key, graph=None)
-            return self._metrics_host(*step_fn(x, y))
         # second step with the same configuration: capture, then replay
         sx, sy = x.clone(), y.clone()
         graph = torch.cuda.CUDAGraph()

@@ -26,6 +26,7 @@ class CpuFcBuffers(object):
         self.bn_sums = torch.zeros(2, W, dtype=torch.float64)
         self.G = self.dU = self.x = self.dact = None
         self._obj = None
+        self.generation = 0  # bumped by every forward that writes these buffers
 
     def new_act(self):
         self.act = torch.zeros(self._act_shape)

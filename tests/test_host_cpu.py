@@ -179,6 +179,24 @@ def test_label_semantics_through_the_wrapper(cpu_backend):
     check_label_semantics_through_the_wrapper(build_cpu_net)
 
 
+def test_backward_after_the_buffers_were_reused_raises(cpu_backend):
+    """One buffer set per (batch, depth, mode): a second train-mode forward before the first one's backward must not
+    silently produce gradients from the wrong activations."""
+    c = Case("c2_boston")
+    net = build_cpu_net(c)
+    x, y = c.t("x"), c.y()
+    net.model.train()
+    act1 = net.model.forward(x)
+    out1 = net.prob_model.fused_objective(None, act1, y, net.f_neg_loglike, c.cfg["N"])
+    with torch.no_grad():
+        net.model.forward(x)          # e.g. get_exact_ELBO(train_bn=True) between forward and backward
+    with pytest.raises(RuntimeError, match="reused"):
+        net._backward(act1, None, out1)
+    act2 = net.model.forward(x)       # the normal order still works
+    out2 = net.prob_model.fused_objective(None, act2, y, net.f_neg_loglike, c.cfg["N"])
+    net._backward(act2, None, out2)
+
+
 def test_q_warmup_and_scheduler(cpu_backend):
     """Callers freeze q_logits for the first epochs (src/DUN/train_fc.py:51-57): a frozen q must not move."""
     c = Case("c2_boston")

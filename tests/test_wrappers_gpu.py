@@ -430,6 +430,24 @@ def test_graphed_step_is_bit_identical_to_eager(name, monkeypatch):
     assert np.array_equal(np.array(net.eval(x, y)), np.array(want_eval), equal_nan=True)
 
 
+def test_graphed_steps_with_a_ragged_last_batch(monkeypatch):
+    """A loader whose last batch is shorter alternates between two step configurations: each gets its own captured
+    graph (kept side by side, replayed from the third epoch on) and the trajectory equals the eager one bit for bit."""
+    c = Case("c2_boston")
+    x, y = c.t("x").cuda(), c.y().cuda()
+    batches = [(x[:200], y[:200]), (x[200:400], y[200:400]), (x[400:], y[400:])]   # 200, 200, 112 rows
+    monkeypatch.setenv("DUN_NO_GRAPH", "1")
+    eager = build_net(c)
+    want = [eager.fit(xb, yb) for _ in range(4) for xb, yb in batches]
+    monkeypatch.delenv("DUN_NO_GRAPH")
+    net = build_net(c)
+    got = [net.fit(xb, yb) for _ in range(4) for xb, yb in batches]
+    assert np.array_equal(np.array(got), np.array(want), equal_nan=True)
+    assert len(net._graph_states) == 2 and all(st["graph"] is not None for st in net._graph_states.values())
+    assert torch.equal(net.model.flat_params, eager.model.flat_params)
+    assert torch.equal(net.prob_model.current_posterior, eager.prob_model.current_posterior)
+
+
 def test_train_fc_epoch_loop_on_device_loader(tmp_path):
     """Config-1 end to end on the GPU: the reference-shaped epoch loop over a device-resident loader."""
     from dun_amd.datasets import DeviceLoader, load_wiggle
