@@ -58,7 +58,8 @@ class FcCtx(C.Structure):
                 ("dact", C.c_void_p), ("g", FcTensors), ("G", C.c_void_p), ("dU", C.c_void_p),
                 ("obj_y", C.c_void_p), ("obj_w", C.c_void_p), ("obj_w_is_logits", C.c_int),
                 ("obj_log_std", C.c_void_p), ("obj_inv_batch", C.c_float), ("obj_dact", C.c_void_p),
-                ("obj_partials", C.c_void_p)]
+                ("obj_partials", C.c_void_p), ("obj_dwpart", C.c_void_p), ("obj_dbpart", C.c_void_p),
+                ("head_grads_from_forward", C.c_int)]
 
 
 _lib = None

@@ -203,6 +203,8 @@ struct HeadObj {
     float* dact;           // [D,B] or nullptr
     double* partials;      // [D,nparts] or nullptr
     int nparts;
+    float* dwpart;         // [D,nparts,K] or nullptr: per-workgroup partial sums of dact[row] * h[row,:] (the head's dw)
+    float* dbpart;         // [D,nparts]: per-workgroup partial sums of dact[row]
 };
 
 __device__ __forceinline__ float head_obj_coef(const HeadObj& o, int d) {
@@ -213,14 +215,41 @@ __device__ __forceinline__ float head_obj_coef(const HeadObj& o, int d) {
 }
 
 // one row's head value -> act, dact, running sum of squared residuals (all lanes hold `a`; lane 0 stores)
-__device__ __forceinline__ void head_obj_row(const HeadObj& o, int d, int B, int row, float a, float coef, int lane,
-                                             float* __restrict__ act_d, double& acc) {
+// -> this row's d loss / d act (0 without an objective)
+__device__ __forceinline__ float head_obj_row(const HeadObj& o, int d, int B, int row, float a, float coef, int lane,
+                                              float* __restrict__ act_d, double& acc) {
     if (lane == 0) act_d[row] = a;
+    float g = 0.f;
     if (o.y) {
         const float r = o.y[row] - a;
-        if (lane == 0 && o.dact) o.dact[(size_t)d * B + row] = coef * r;
+        g = coef * r;
+        if (lane == 0 && o.dact) o.dact[(size_t)d * B + row] = g;
         acc += (double)(r * r);
     }
+    return g;
+}
+
+// The head's weight gradient from the forward pass: for the ELBO d loss / d act of a row is known the moment its head
+// value is (q is known a priori), and the row of h is in registers -- so dw_out = sum_rows dact[row] * h[row,:] is
+// accumulated per lane over the rows a wavefront walks (fp32, <= 32 rows), the four wavefronts of a workgroup are added
+// in a fixed order through LDS, and one [K] partial per workgroup and depth is left for a fp64 reduction at the start
+// of backward.  This is what removes head_bwd's re-read of all hidden states (27 GB at the wide configuration).
+template <int NCH>
+__device__ __forceinline__ void head_dw_finish(const HeadObj& o, int d, const f32x4 (&gw)[NCH], float gb, int K,
+                                               float* gwred /* [4][NCH*256] */, float* gbred /* [4] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) *reinterpret_cast<f32x4*>(gwred + wv * (NCH * 256) + (j * 64 + lane) * 4) = gw[j];
+    if (lane == 0) gbred[wv] = gb;
+    __syncthreads();
+    float* dst = o.dwpart + ((size_t)d * o.nparts + blockIdx.x) * K;
+    for (int c = threadIdx.x * 4; c < K; c += 1024) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(gwred + c);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(gwred + w * (NCH * 256) + c);
+        *reinterpret_cast<f32x4*>(dst + c) = t;
+    }
+    if (threadIdx.x == 0) o.dbpart[(size_t)d * o.nparts + blockIdx.x] = (gbred[0] + gbred[1]) + (gbred[2] + gbred[3]);
 }
 
 __device__ __forceinline__ void head_obj_finish(const HeadObj& o, int d, double acc, double* red) {
@@ -231,7 +260,7 @@ __device__ __forceinline__ void head_obj_finish(const HeadObj& o, int d, double 
     if (threadIdx.x == 0) o.partials[(size_t)d * o.nparts + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int NCH, bool NT>
+template <int NCH, bool NT, bool DW>
 __global__ __launch_bounds__(256) void bn_apply_head_kernel(const float* __restrict__ Z, const float* __restrict__ Hin,
                                                             float* __restrict__ Hout, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int stat_is_var, float eps,
@@ -241,10 +270,15 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(const float* __restr
                                                             const float* __restrict__ b_out, float* __restrict__ act_d,
                                                             HeadObj o) {
     __shared__ double red[4];
+    __shared__ __attribute__((aligned(16))) float gwred[DW ? 4 * NCH * 256 : 4];
+    __shared__ float gbred[4];
     constexpr int W = NCH * 256;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    f32x4 sc[NCH], mu[NCH], sh[NCH], wo[NCH];
+    f32x4 sc[NCH], mu[NCH], sh[NCH], wo[NCH], gw[NCH];
+    float gb = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) gw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = (j * 64 + lane) * 4;
@@ -277,14 +311,21 @@ __global__ __launch_bounds__(256) void bn_apply_head_kernel(const float* __restr
             if (residual) v += h[j];
             st4_stream<NT>(Hout + off + j * 256, v);
             dot += (v[0] * wo[j][0] + v[1] * wo[j][1]) + (v[2] * wo[j][2] + v[3] * wo[j][3]);
+            if (DW) z[j] = v;  // the row of h_out is needed once more, for the head's weight gradient
         }
-        head_obj_row(o, o.d, B, row, wave_allsum(dot) + b0, coef, lane, act_d, acc);
+        const float g = head_obj_row(o, o.d, B, row, wave_allsum(dot) + b0, coef, lane, act_d, acc);
+        if (DW) {
+            gb += g;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) gw[j] += g * z[j];
+        }
     }
     head_obj_finish(o, o.d, acc, red);
+    if (DW) head_dw_finish<NCH>(o, o.d, gw, gb, W, gwred, gbred);
 }
 
 // The shared head alone (O == 1) with the same likelihood epilogue: depth blockIdx.y of H [.,B,K]; any K.
-template <bool VEC, bool NT>
+template <bool VEC, bool NT, bool DW = false>
 __global__ __launch_bounds__(256) void head_obj_kernel(const float* __restrict__ H, const float* __restrict__ w_out,
                                                        const float* __restrict__ b_out, int B, int K,
                                                        float* __restrict__ act, HeadObj o) {
@@ -297,10 +338,28 @@ __global__ __launch_bounds__(256) void head_obj_kernel(const float* __restrict__
     const float coef = head_obj_coef(o, d);
     const float b0 = b_out[0];
     double acc = 0.0;
+    // DW (host: VEC, K % 256 == 0, K <= 2048): the row stays in registers for the head's weight gradient
+    __shared__ __attribute__((aligned(16))) float gwred[DW ? 4 * 8 * 256 : 4];
+    __shared__ float gbred[4];
+    f32x4 gw[8], hv8[8];
+    float gb = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int row = wave; row < B; row += nwaves) {
         const float* h = Hd + (size_t)row * K;
         float dot = 0.f;
-        if (VEC) {
+        if (DW) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = (j * 64 + lane) * 4;
+                hv8[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (k < K) {
+                    hv8[j] = ld4_stream<NT>(h + k);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w_out + k);
+                    dot += (hv8[j][0] * wv[0] + hv8[j][1] * wv[1]) + (hv8[j][2] * wv[2] + hv8[j][3] * wv[3]);
+                }
+            }
+        } else if (VEC) {
             for (int k = lane * 4; k < K; k += 256) {
                 const f32x4 hv = ld4_stream<NT>(h + k), wv = *reinterpret_cast<const f32x4*>(w_out + k);
                 dot += (hv[0] * wv[0] + hv[1] * wv[1]) + (hv[2] * wv[2] + hv[3] * wv[3]);
@@ -309,9 +368,46 @@ __global__ __launch_bounds__(256) void head_obj_kernel(const float* __restrict__
             for (int k = lane; k < K; k += 64) dot += h[k] * w_out[k];
         }
         // (dact / partials are indexed by the global depth; act_d is already offset)
-        head_obj_row(o, d, B, row, wave_allsum(dot) + b0, coef, lane, act_d, acc);
+        const float g = head_obj_row(o, d, B, row, wave_allsum(dot) + b0, coef, lane, act_d, acc);
+        if (DW) {
+            gb += g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gw[j] += g * hv8[j];
+        }
     }
     head_obj_finish(o, d, acc, red);
+    if (DW) {
+        // (the 8-chunk LDS image is K-strided per wavefront as in head_dw_finish<8>; columns >= K hold zeros)
+        head_dw_finish<8>(o, d, gw, gb, K, gwred, gbred);
+    }
+}
+
+// stage 1 of dw_out = sum over all (depth, workgroup) partials: grid (K/256, row splits); a thread owns four columns,
+// the four wavefronts split the rows of the split, fp64 from the first add on; out double [splits][K]
+__global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float* __restrict__ part, int P, int K, int rows_per_split,
+                                                             double* __restrict__ out) {
+    __shared__ double red[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;  // this thread's four columns (K % 256 == 0: always inside)
+    const int r0 = blockIdx.y * rows_per_split, r1 = min(P, r0 + rows_per_split);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int r = r0 + wv; r < r1; r += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)r * K + c);
+        a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+    }
+    red[wv][lane * 4 + 0] = a0; red[wv][lane * 4 + 1] = a1; red[wv][lane * 4 + 2] = a2; red[wv][lane * 4 + 3] = a3;
+    __syncthreads();
+    const int t = threadIdx.x;  // 256 threads <-> the 256 columns of this block
+    out[(size_t)blockIdx.y * K + blockIdx.x * 256 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
+// db_out = sum of n floats in fp64, one workgroup, fixed order
+__global__ __launch_bounds__(256) void sum_to_scalar_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += (double)v[i];
+    const double t = block_sum<256, double>(a, red);
+    if (threadIdx.x == 0) out[0] = (float)t;
 }
 
 // per-slab column sums of g and g*xhat (xhat = (z-mean)*rstd): partials [2][P][W]
@@ -555,6 +651,8 @@ static inline int obj_nparts(int B) {
     return n < 1 ? 1 : (n > 512 ? 512 : n);
 }
 
+static bool head_fused(const dun_fc_ctx* c);
+
 static HeadObj make_obj(const dun_fc_ctx* c, int d) {
     HeadObj o;
     memset(&o, 0, sizeof(o));
@@ -569,6 +667,10 @@ static HeadObj make_obj(const dun_fc_ctx* c, int d) {
         o.inv_batch = c->obj_inv_batch;
         o.dact = c->obj_w ? c->obj_dact : nullptr;
         o.partials = c->obj_partials;
+        if (o.dact && c->obj_dwpart && c->obj_dbpart && head_fused(c)) {
+            o.dwpart = c->obj_dwpart;
+            o.dbpart = c->obj_dbpart;
+        }
     }
     return o;
 }
@@ -590,7 +692,11 @@ static int head_obj(const dun_fc_ctx* c, int d0, int ndepth, hipStream_t s) {
     const dim3 grid(obj_nparts(c->B), ndepth);
     const bool vec = c->W % 4 == 0 && aligned16(H) && aligned16(c->p.w_out);
     const bool nt = stream_nt((size_t)ndepth * c->B * c->W * 4);
-    if (vec && nt)
+    if (o.dwpart != nullptr && vec && nt)  // (dwpart is only set where head_fused: K % 256 == 0, K <= 2048, aligned)
+        hipLaunchKernelGGL((head_obj_kernel<true, true, true>), grid, dim3(256), 0, s, H, c->p.w_out, c->p.b_out, c->B, c->W, act, o);
+    else if (o.dwpart != nullptr && vec)
+        hipLaunchKernelGGL((head_obj_kernel<true, false, true>), grid, dim3(256), 0, s, H, c->p.w_out, c->p.b_out, c->B, c->W, act, o);
+    else if (vec && nt)
         hipLaunchKernelGGL((head_obj_kernel<true, true>), grid, dim3(256), 0, s, H, c->p.w_out, c->p.b_out, c->B, c->W, act, o);
     else if (vec)
         hipLaunchKernelGGL((head_obj_kernel<true, false>), grid, dim3(256), 0, s, H, c->p.w_out, c->p.b_out, c->B, c->W, act, o);
@@ -685,19 +791,19 @@ static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream
         const HeadObj o = make_obj(c, i + 1);
         float* act_d = c->act + (size_t)(i + 1) * B;
         const dim3 grid(obj_nparts(B));
+#define BAH1(N, NTF, DWF)                                                                                              \
+    hipLaunchKernelGGL((bn_apply_head_kernel<N, NTF, DWF>), grid, dim3(256), 0, s, Z, hin, hout, mean, stat, is_var,     \
+                       c->bn_eps, gamma, beta, B, c->residual, c->p.w_out, c->p.b_out, act_d, o)
 #define BAH(N)                                                                                                         \
     case N:                                                                                                            \
-        if (nt)                                                                                                        \
-            hipLaunchKernelGGL((bn_apply_head_kernel<N, true>), grid, dim3(256), 0, s, Z, hin, hout, mean, stat, is_var, \
-                               c->bn_eps, gamma, beta, B, c->residual, c->p.w_out, c->p.b_out, act_d, o);               \
-        else                                                                                                           \
-            hipLaunchKernelGGL((bn_apply_head_kernel<N, false>), grid, dim3(256), 0, s, Z, hin, hout, mean, stat, is_var, \
-                               c->bn_eps, gamma, beta, B, c->residual, c->p.w_out, c->p.b_out, act_d, o);               \
+        if (o.dwpart != nullptr) { if (nt) BAH1(N, true, true); else BAH1(N, false, true); }                          \
+        else { if (nt) BAH1(N, true, false); else BAH1(N, false, false); }                                            \
         break;
         switch (W / 256) {
             BAH(1) BAH(2) BAH(3) BAH(4) BAH(5) BAH(6) BAH(7) BAH(8)
         }
 #undef BAH
+#undef BAH1
         DUN_LAUNCH_CHECK();
         return DUN_OK;
     }
@@ -741,9 +847,27 @@ static int bwd_begin(const dun_fc_ctx* c, hipStream_t s) {
     const int rows = (c->depth + 1) * c->B;
     int rc = transpose_block_weights(c, s);
     if (rc) return rc;
-    rc = head_backward(c->H, c->p.w_out, c->dact, rows, c->W, c->O, c->g.w_out, c->g.b_out, nullptr, c->ws,
+    if (c->head_grads_from_forward) {
+        // dw_out / db_out partials were accumulated by the forward's head kernels (dact = the forward's own obj_dact):
+        // add them up in fp64, two stages, fixed order -- no pass over the hidden states
+        DUN_REQUIRE(c->obj_dwpart && c->obj_dbpart && c->O == 1 && head_fused(c),
+                    "dun_fc_bwd_begin: head_grads_from_forward without the forward's partial sums");
+        const int P = (c->depth + 1) * obj_nparts(c->B), K = c->W;
+        const int rps = ceil_div(P, 256), splits = ceil_div(P, rps);
+        DUN_REQUIRE((size_t)splits * K * 2 <= c->ws_floats, "dun_fc_bwd_begin: workspace too small");
+        double* stage = reinterpret_cast<double*>(c->ws);
+        hipLaunchKernelGGL(head_dw_reduce_kernel, dim3(K / 256, splits), dim3(256), 0, s, c->obj_dwpart, P, K, rps, stage);
+        DUN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(reduce_cols_kernel<double>, dim3(ceil_div(K, RCX), 1), dim3(256), 0, s, stage, splits, K,
+                           (double*)nullptr, c->g.w_out, (float*)nullptr);
+        DUN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, s, c->obj_dbpart, P, c->g.b_out);
+        DUN_LAUNCH_CHECK();
+    } else {
+        rc = head_backward(c->H, c->p.w_out, c->dact, rows, c->W, c->O, c->g.w_out, c->g.b_out, nullptr, c->ws,
                            c->ws_floats, s);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     const size_t n = (size_t)c->B * c->W;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(rank_init_kernel, dim3(grid), dim3(256), 0, s, c->G, c->dact + (size_t)c->depth * c->B * c->O,

@@ -6,6 +6,7 @@ Everything the rest of the package computes on the hot path goes through the obj
 stand-in (tests/cpu_backend.py); nothing in the package itself ever installs another backend.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -35,6 +36,7 @@ class FcBuffers(object):
         self.dact = None
         self._obj = None
         self.generation = 0  # bumped by every forward that writes these buffers
+        self._dwpart = self._dbpart = None
         c = L.FcCtx()
         c.B, c.din, c.W, c.O, c.L = B, din, W, O, Lyr
         c.residual, c.train, c.depth = int(model.residual), int(train), depth
@@ -66,11 +68,18 @@ class FcBuffers(object):
     def set_dact(self, dact):
         self.dact = dact
         self.c.dact = L.f32(dact)
+        # Backward with the very d loss / d act the forward's head kernels wrote: the head's dw / db partial sums of
+        # that forward are valid, backward adds them up instead of re-reading every hidden state
+        o = self._obj
+        self.c.head_grads_from_forward = int(o is not None and o.dact is not None and self.c.obj_dwpart is not None
+                                             and dact.data_ptr() == o.dact.data_ptr() and dact.numel() == o.dact.numel())
 
     def set_objective(self, spec):
         """Fold the Gaussian likelihood pass into the head kernels of the next forward (spec: probability.HeadObjective,
         or None for a plain forward).  Its outputs are fresh tensors per forward, handed over through the spec."""
         c = self.c
+        c.obj_dwpart = c.obj_dbpart = None
+        c.head_grads_from_forward = 0
         if spec is None:
             c.obj_y = c.obj_w = c.obj_log_std = c.obj_dact = c.obj_partials = None
             self._obj = None
@@ -88,6 +97,13 @@ class FcBuffers(object):
         c.obj_dact = None if spec.dact is None else L.f32(spec.dact)
         c.obj_partials = L.ptr(spec.partials)
         self._obj = spec  # keeps the tensors behind the raw pointers alive until the next forward
+        if spec.dact is not None and self.train and self.head_fused and os.environ.get("DUN_HEAD_DW_IN_FORWARD", "1") != "0":
+            # the head's weight / bias gradient is accumulated by the forward's head kernels (per-workgroup partials,
+            # kept with the buffers: [D, nparts, W] floats, 214 MB at the wide configuration)
+            if self._dwpart is None:
+                self._dwpart = torch.empty(D, nparts, self.H.shape[2], device=dev, dtype=torch.float32)
+                self._dbpart = torch.empty(D, nparts, device=dev, dtype=torch.float32)
+            c.obj_dwpart, c.obj_dbpart = L.f32(self._dwpart), L.f32(self._dbpart)
 
     @property
     def head_fused(self):

@@ -230,6 +230,15 @@ typedef struct dun_fc_ctx {
     float* obj_dact;          /* [depth+1,B] d(-objective/N)/d act, or NULL */
     double* obj_partials;     /* [depth+1, dun_fc_obj_num_partials(B, O)]: per-workgroup sums of (y - act)^2, the layout
                                  dun_ll_reduce / dun_depth_finalize_partials take */
+    /* Optional, with obj_w and where dun_fc_head_is_fused: the head's weight / bias gradient from the forward pass.
+     * d loss / d act of a row is known as soon as its head value is, and the row of h is in registers then, so
+     * sum_rows dact[row] * h[row,:] is accumulated there: per-workgroup partials [depth+1, P, W] and [depth+1, P],
+     * P = dun_fc_obj_num_partials.  A backward whose `dact` IS the forward's obj_dact sets head_grads_from_forward and
+     * dun_fc_bwd_begin / dun_fc_backward add the partials up instead of streaming every hidden state once more
+     * (dun_head_backward's pass; autograd's mm nodes behind src/DUN/stochastic_fc_models.py:66,69). */
+    float* obj_dwpart;
+    float* obj_dbpart;
+    int head_grads_from_forward;
 } dun_fc_ctx;
 
 size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L);

@@ -312,6 +312,13 @@ def test_likelihood_pass_inside_the_head_matches_the_separate_pass(din, W, L, B,
     for _ in range(2):
         ra, rb = a.fit(xa, ya), b.fit(xa, ya)
         assert np.allclose(ra, rb, rtol=2e-5, equal_nan=True), (ra, rb)
+        # the head's weight / bias gradient: accumulated by the forward's head kernels (a, VI on fused widths) against
+        # dun_head_backward's pass over the hidden states (b)
+        for k in ("w_out", "b_out", "w_in"):
+            assert rel_err(a.model.stacked_grad[k].cpu(), b.model.stacked_grad[k].cpu()) < 2e-5, k
+    if vi and L > 0 and W % 256 == 0:
+        buf = [v for key, v in a.model._fc_cache.items() if key[2]][0]
+        assert buf.c.head_grads_from_forward == 1 and buf.c.obj_dwpart is not None
     assert rel_err(a.model.flat_params.cpu(), b.model.flat_params.cpu()) < 1e-5
     assert np.allclose(a.eval(xa, ya), b.eval(xa, ya), rtol=1e-5, equal_nan=True)
 
