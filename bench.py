@@ -148,11 +148,20 @@ def image_head_rooflines(net, B_local, reps=20):
     return out
 
 
-def timed(fn, n, stream_sync=True):
-    """Average duration (ms) of n back-to-back calls, HIP events on the current stream."""
+def timed(fn, n, stream_sync=True, settle_ms=60.0):
+    """Average duration (ms) of n back-to-back calls, HIP events on the current stream, taken once the launch has
+    been repeating for about settle_ms: after an idle gap (a host-side allocation, a first use of the RNG) the first
+    launches run at lower clocks -- the C3 dX GEMM measured 4.9, 4.7, 4.4, 4.3, 4.2, 4.1 ms before settling at 3.94
+    (profiles/r02_dx_first_launches.txt) -- and a five-launch average taken there reports the ramp, not the kernel."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    for _ in range(max(1, min(200, int(settle_ms / max(e0.elapsed_time(e1), 1e-3))))):
+        fn()
     e0.record()
     for _ in range(n):
         fn()

@@ -35,6 +35,13 @@ for rep in range(2):
     wT = w.t().contiguous()
     ms = timed(lambda: be.gemm(Z, wT, B, W, W, a_kcontig=True, b_kcontig=True, R=out, U=u1, V=v1, out=out), 10)
     print("dX   %.3f ms  %.1f TF  (same, against a transposed copy of W: both operands K-contiguous)" % (ms, fl / ms / 1e9))
+    G2 = torch.randn(B, W, device="cuda", generator=g) if rep == 0 else G2
+    ms = timed(lambda: be.gemm(Z, wT, B, W, W, a_kcontig=True, b_kcontig=True, R=G2, U=u1, V=v1, out=out, bn=(H, mean, rstd)), 10)
+    print("dX   %.3f ms  %.1f TF  (as the step runs it: transposed W, residual read from another plane, + statistics epilogue)" % (ms, fl / ms / 1e9))
+    Zs = Z * (torch.rand(B, W, device="cuda", generator=g) < 0.5)
+    ms = timed(lambda: be.gemm(Zs, wT, B, W, W, a_kcontig=True, b_kcontig=True, R=G2, U=u1, V=v1, out=out, bn=(H, mean, rstd)), 10)
+    print("dX   %.3f ms  %.1f TF  (same, half of the A operand zero like a ReLU-masked dU)" % (ms, fl / ms / 1e9))
+    del Zs
     ms = timed(lambda: be.gemm(Z, H, W, W, B, a_kcontig=False, b_kcontig=False, out=gw), 10)
     print("dW   %.3f ms  %.1f TF" % (ms, fl / ms / 1e9), flush=True)
     ms = timed(lambda: be.gemm(Z, H, W, W, B, a_kcontig=False, b_kcontig=False, out=gw, splitk_ws=skws), 10)
