@@ -129,6 +129,10 @@ class arq_uncert_fc_resnet(nn.Module):
                 bn.running_var = rv[i]
                 bn.num_batches_tracked = nbt[i]
         self.flat_params, self.flat_grads = flat, gflat
+        # captured steps hold the addresses of the buffers they were captured on: a rebuilt flat buffer (load_state_dict,
+        # .to()) may land on the old parameter address while its gradient buffer does not, so the wrappers key their
+        # graphs on this counter too
+        self._flat_generation = self.__dict__.get("_flat_generation", 0) + 1
         self.running_mean, self.running_var, self.num_batches_tracked = rm, rv, nbt
         self._fc_cache = {}
         # every parameter of the module tree lives in the flat buffer (what the whole-step hipGraph relies on)

@@ -169,8 +169,8 @@ class DUN(BaseNet):
         g = self.optimizer.param_groups[0]
         q = getattr(self.prob_model, "q_logits", None)
         return (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype, g["lr"], g["momentum"], g["weight_decay"],
-                None if q is None else bool(q.requires_grad), model.flat_params.data_ptr(), id(self.optimizer),
-                float(self.N_train), type(self).__name__)
+                None if q is None else bool(q.requires_grad), model.flat_params.data_ptr(), getattr(model, "_flat_generation", 0),
+                id(self.optimizer), float(self.N_train), type(self).__name__)
 
     graph_cache_size = 4  # captured steps kept per wrapper (full batch, ragged tail batch, a second loader, ...)
 

@@ -98,3 +98,15 @@ class BaseNet(object):
         if "best_err" in state:
             return self.epoch, state["best_err"]
         return self.epoch
+
+    def save_state(self, filename, best_err=None):
+        """Tensors-only checkpoint (dun_amd.checkpoint): state dicts instead of pickled objects."""
+        from .checkpoint import save_state
+        cprint("c", "Writting %s\n" % filename)
+        save_state(self, filename, best_err)
+
+    def load_state(self, filename, to_cpu=False):
+        """Restore from save_state's file, or from a reference checkpoint converted by
+        scripts/export_reference_checkpoint.py.  Executes nothing from the file."""
+        from .checkpoint import load_state
+        return load_state(self, filename, to_cpu=to_cpu)

@@ -481,6 +481,33 @@ def prior_cases():
                                w_prior=wp), xc, yc)
 
 
+def checkpoint_case():
+    """Checkpoint ingestion: a reference DUN_VI with a MultiStepLR schedule is trained for two steps
+    and one epoch tick, its state written in the tensors-only layout (dun_amd.checkpoint.net_state reads the
+    reference's own objects), and training continued -- a step, an epoch tick that crosses a milestone, another step.
+    The continuation is what a wrapper restored from the file must reproduce (momentum and schedule included)."""
+    from dun_amd.checkpoint import net_state
+    cfg = dict(din=5, O=1, W=16, L=3, N=96, lr=5e-2, momentum=0.9, wd=1e-4, regression=True, vi=True, seed=11)
+    x, y = synthetic_regression(64, cfg["din"], 21)
+    net = build(cfg)
+    quiet(net.make_scheduler, gamma=0.1, milestones=[2, 4])
+    out = {"meta": json.dumps(cfg), "x": npy(x), "y": npy(y)}
+    for _ in range(2):
+        net.fit(x, y)
+    net.update_lr()
+    torch.save(net_state(net, best_err=0.25), os.path.join(HERE, "ckpt_ref_vi.pt"))
+    rets = [net.fit(x, y)]
+    net.update_lr()  # epoch 2: first milestone, lr x 0.1
+    out["lr_after"] = np.array(net.optimizer.param_groups[0]["lr"])
+    rets.append(net.fit(x, y))
+    out["fit/ret"] = np.array(rets, dtype=np.float64)
+    put_sd(out, "fit/sd/", net.model.state_dict())
+    out["fit/q_logits"] = npy(net.prob_model.q_logits)
+    out["fit/log_std"] = npy(net.f_neg_loglike.log_std)
+    np.savez_compressed(os.path.join(HERE, "ckpt_ref_vi.npz"), **out)
+    print("wrote ckpt_ref_vi", rets, float(out["lr_after"]))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "prior":
         prior_cases()
@@ -521,6 +548,7 @@ def main():
     run_case("cls_fc_mll", dict(base, regression=False, vi=False, din=20, O=10, W=64, L=4, N=256, lr=0.05,
                                 momentum=0.9), xc, yc)
     prior_cases()
+    checkpoint_case()
     label_cases()
     edge_cases()
     head_case()

@@ -247,6 +247,30 @@ def test_seed_matched_construction_and_checkpoint(tmp_path):
     assert np.allclose(r1, r2, rtol=1e-6)
 
 
+def test_reference_state_checkpoint_on_the_device(tmp_path):
+    """tests/test_checkpoint_cpu.py on the real kernels: the state written from the reference's objects is ingested into a
+    device wrapper (per-parameter momentum scattered into the flat buffer of the fused SGD kernel, schedule restored)
+    and the continued training -- graphed steps included: the net is small -- equals the reference's; a round trip
+    through save_state / load_state on the device continues bit-identically."""
+    import os
+    from tests.test_checkpoint_cpu import build, continue_like_reference
+    from tests.util import GOLDEN
+    c = Case("ckpt_ref_vi")
+    net = build(c.cfg, seed=99, cuda=True)
+    x, y = c.t("x").cuda(), c.t("y").cuda()
+    for _ in range(3):
+        net.fit(x, y)  # eager, capture, replay: the captured step must not survive the load
+    assert quiet(net.load_state, os.path.join(GOLDEN, "ckpt_ref_vi.pt")) == (1, 0.25)
+    continue_like_reference(net, c, dev="cuda")
+    path = str(tmp_path / "state.pt")
+    quiet(net.save_state, path)
+    other = build(c.cfg, seed=5, cuda=True)
+    assert quiet(other.load_state, path) == net.epoch
+    for _ in range(3):
+        assert net.fit(x, y) == other.fit(x, y)
+    assert torch.equal(net.model.flat_params, other.model.flat_params)
+
+
 def test_label_semantics_through_the_wrapper():
     from tests.test_host_cpu import check_label_semantics_through_the_wrapper
     check_label_semantics_through_the_wrapper(build_net)
