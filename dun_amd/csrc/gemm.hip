@@ -259,7 +259,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, f32x16 (&acc)
                     if (has_r) v += aux[mi][ni][r];
                     if (has_u1) {
                         v += uu[mi][r] * v1;
-                    } else if (p.U != nullptr) {
+                    } else if (!BNS && p.U != nullptr) {  // (rank-O with the statistics epilogue: refused on the host)
                         const int row = Cio.rowu(mi, r) + 4 * h;
                         for (int o = 0; o < p.O; ++o) v += p.U[(size_t)row * p.O + o] * p.V[(size_t)o * p.ldv + col];
                     }
@@ -624,12 +624,29 @@ __device__ __forceinline__ void read_frag_half(const float* lds, int row, int t,
 // s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt = bits [3:0] and [15:14]; expcnt / lgkmcnt fields left at "no wait")
 #define DUN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 
+#ifdef DUN_GEMM_TIMING
+// Diagnostic build only (scripts/gemm_phases.py builds its own library with -DDUN_GEMM_TIMING): every workgroup of the
+// four-stage kernel records the shader clock at its start, at its first MFMA, at the end of the K loop and at its end,
+// plus the hardware slot it ran on.  Not part of the shipped library.
+__device__ unsigned long long* g_gemm_timing = nullptr;
+#define DUN_TSTAMP(i) do { if (tid == 0 && g_gemm_timing) tstamp[i] = clock64(); } while (0)
+#else
+#define DUN_TSTAMP(i) do { } while (0)
+#endif
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) float smem[4 * STAGE];
-
     const int nwg = p.gridM * p.gridN;
-    int bid = blockIdx.x;
+    // One tile per workgroup when the grid has a workgroup per tile; a smaller grid (DUN_GEMM_PERSIST) walks the tiles
+    // with stride gridDim.x -- tile t of a workgroup on XCD x still satisfies t % 8 == x, so the XCD grouping of the
+    // remap below is the same either way.
+    for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
+#ifdef DUN_GEMM_TIMING
+    unsigned long long tstamp[4];
+    if (threadIdx.x == 0 && g_gemm_timing) tstamp[0] = clock64();
+#endif
+    int bid = tile;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -663,6 +680,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     }
     if (nh >= 3) DUN_WAIT_VMCNT(8); else DUN_WAIT_VMCNT(4);
     __builtin_amdgcn_s_barrier();
+    DUN_TSTAMP(1);
 
     // Every kernel argument the epilogue needs is pulled into SGPRs HERE: a scalar (kernel-argument) load still
     // pending at the loop entry shares lgkmcnt with the LDS reads, the counter is then no longer in-order for the
@@ -723,6 +741,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     if (j + 1 < nh) { DUN_HALF_STEP(j, true, false, false); ++j; } // half nh-2: the last DMA must land
     DUN_HALF_STEP(j, false, false, false);                         // half nh-1
 #undef DUN_HALF_STEP
+    DUN_TSTAMP(2);
     __syncthreads();  // the epilogue reuses the LDS for the column statistics
     if (p.ksplit > 1) {
         GemmP q = p;  // raw partial sum of this K range; splitk_sum_kernel adds the ranges in order
@@ -733,7 +752,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     } else {
         gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
     }
+#ifdef DUN_GEMM_TIMING
+    if (tid == 0 && g_gemm_timing) {
+        __builtin_amdgcn_s_waitcnt(0);  // the epilogue's stores have left the wave
+        tstamp[3] = clock64();
+        unsigned long long* o = g_gemm_timing + 6 * ((size_t)blockIdx.y * nwg + tile);
+        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(tstamp[i], o + i);
+        __builtin_nontemporal_store((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4), o + 4);    // HW_ID
+        __builtin_nontemporal_store((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20), o + 5);   // XCC_ID
+    }
+#endif
+    if (tile + (int)gridDim.x < nwg) __syncthreads();  // the next tile's prologue overwrites the LDS the epilogue read
+    }
 }
+
+#ifdef DUN_GEMM_TIMING
+extern "C" int dun_debug_gemm_timing(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(dun::g_gemm_timing), &buf, sizeof(buf));
+}
+#endif
 
 // C[m][n] = part[0][m][n] + part[1][m][n] + ... (fixed order: reproducible)
 __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ part, int ksplit, int M, int N,
@@ -767,9 +804,12 @@ static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream
         const size_t n4 = (size_t)p.M * p.N / 4;
         const int g = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
         hipLaunchKernelGGL(splitk_sum_kernel, dim3(g), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
-    } else if (dma)
-        hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
-    else {
+    } else if (dma) {
+        // A/B hook: DUN_GEMM_PERSIST=n launches n workgroups (a multiple of 8, e.g. 512 = two per CU) that walk the tiles
+        static const int env_persist = getenv("DUN_GEMM_PERSIST") ? atoi(getenv("DUN_GEMM_PERSIST")) : 0;
+        const int g = (env_persist >= 8 && env_persist % 8 == 0 && env_persist < grid) ? env_persist : grid;
+        hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(g), dim3(256), 0, s, p);
+    } else {
         const dim3 g2(grid, p.ksplit > 1 ? p.ksplit : 1);
         if (small && vec)
             hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 1>), g2, dim3(256), 0, s, p);
@@ -874,8 +914,8 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
         static const int env_rinit = getenv("DUN_GEMM_RINIT") ? atoi(getenv("DUN_GEMM_RINIT")) : 1;
         p.gm = (dma && env_gm > 1) ? env_gm : 1;
         const bool can_seed = d->R && !d->bias && !d->relu && p.ksplit == 1;
-        if (d->bnz && (d->bias || d->relu || d->colstats || (d->R && !can_seed))) {
-            set_error("dun_gemm_f32: bnz together with bias / ReLU / colstats is not implemented");
+        if (d->bnz && (d->bias || d->relu || d->colstats || (d->R && !can_seed) || (d->U && d->O != 1))) {
+            set_error("dun_gemm_f32: bnz together with bias / ReLU / colstats / a rank-O update with O > 1 is not implemented");
             return DUN_ERR_UNSUPPORTED;
         }
         p.rinit = (can_seed && (env_rinit || d->bnz)) ? 1 : 0;  // (the statistics epilogue shares the residual's registers)

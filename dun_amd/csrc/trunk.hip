@@ -880,7 +880,9 @@ static int bwd_begin(const dun_fc_ctx* c, hipStream_t s) {
 // tile of g it has just computed is in registers (one read of Z_i instead of a pass over g and Z_i): every block but the
 // deepest, whose incoming gradient does not come out of a GEMM.  DUN_BWD_STATS_IN_GEMM=0 keeps the separate pass (A/B).
 static const bool g_stats_in_gemm = !(getenv("DUN_BWD_STATS_IN_GEMM") && getenv("DUN_BWD_STATS_IN_GEMM")[0] == '0');
-static inline bool stats_from_gemm(const dun_fc_ctx* c, int i) { return g_stats_in_gemm && i < c->L - 1; }
+// (one head output only: the statistics epilogue is compiled without the general rank-O update, whose per-row address
+// registers made it spill its Z tile one HBM round trip at a time)
+static inline bool stats_from_gemm(const dun_fc_ctx* c, int i) { return g_stats_in_gemm && c->O == 1 && i < c->L - 1; }
 
 static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
     const int W = c->W, B = c->B;
