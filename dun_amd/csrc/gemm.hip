@@ -623,6 +623,13 @@ __device__ __forceinline__ void read_frag_half(const float* lds, int row, int t,
 
 // s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt = bits [3:0] and [15:14]; expcnt / lgkmcnt fields left at "no wait")
 #define DUN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+// s_waitcnt lgkmcnt(0) alone.  Placed behind each group of 16 MFMAs, where the fragment reads issued in front of that
+// group landed long ago, so it costs nothing -- but it tells the compiler that nothing is pending when the next
+// prefetch goes out.  Without it the M/N-contiguous operand images (eight ds_read2_b32 per group) have 16 LDS reads
+// outstanding at the first MFMA of a group, one more than the 4-bit counter can express, and the compiler falls back
+// to lgkmcnt(0) THERE: the prefetch it just issued is waited for instead of hidden (dW: K loop at 0.908 of peak
+// against 0.942 for the K-contiguous images, whose four ds_read_b128 per group stay countable).
+#define DUN_WAIT_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
 #ifdef DUN_GEMM_TIMING
 // Diagnostic build only (scripts/gemm_phases.py builds its own library with -DDUN_GEMM_TIMING): every workgroup of the
@@ -637,16 +644,13 @@ __device__ unsigned long long* g_gemm_timing = nullptr;
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     __shared__ __attribute__((aligned(16))) float smem[4 * STAGE];
-    const int nwg = p.gridM * p.gridN;
-    // One tile per workgroup when the grid has a workgroup per tile; a smaller grid (DUN_GEMM_PERSIST) walks the tiles
-    // with stride gridDim.x -- tile t of a workgroup on XCD x still satisfies t % 8 == x, so the XCD grouping of the
-    // remap below is the same either way.
-    for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
 #ifdef DUN_GEMM_TIMING
-    unsigned long long tstamp[4];
+    unsigned long long tstamp[5];
     if (threadIdx.x == 0 && g_gemm_timing) tstamp[0] = clock64();
 #endif
-    int bid = tile;
+
+    const int nwg = p.gridM * p.gridN;
+    int bid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -694,6 +698,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     for (int mi = 0; mi < 2; ++mi) read_frag_half<A_KC>(smem, wr * 64 + mi * 32 + li, 0, h, fa[0][mi]);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) read_frag_half<B_KC>(smem + HALF_TILE, wc * 64 + ni * 32 + li, 0, h, fb[0][ni]);
+    DUN_WAIT_LGKMCNT0();  // (the loop is entered with nothing pending on either path: see DUN_WAIT_LGKMCNT0)
 
     // One half tile.  NEXT: half j+1 exists; INFLIGHT: half j+2 was issued (so it may stay in flight); ISSUE: half j+3
     // exists.  Compile-time flags: a run-time branch around the fragment prefetch would make the compiler wait for
@@ -712,6 +717,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
                 _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][mi][e], fb[0][ni][e], acc[mi][ni], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_WAIT_LGKMCNT0();                                                                                           \
         if (NEXT) {                                                                                                    \
             if (INFLIGHT) DUN_WAIT_VMCNT(4); else DUN_WAIT_VMCNT(0);                                                   \
             __builtin_amdgcn_s_barrier();                                                                              \
@@ -732,6 +738,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
             _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
                 _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][mi][e], fb[1][ni][e], acc[mi][ni], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_WAIT_LGKMCNT0();                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
 
@@ -754,16 +762,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     }
 #ifdef DUN_GEMM_TIMING
     if (tid == 0 && g_gemm_timing) {
-        __builtin_amdgcn_s_waitcnt(0);  // the epilogue's stores have left the wave
+        tstamp[4] = clock64();          // the epilogue's last instruction is issued
+        __builtin_amdgcn_s_waitcnt(0);  // ... and its stores have been acknowledged
         tstamp[3] = clock64();
-        unsigned long long* o = g_gemm_timing + 6 * ((size_t)blockIdx.y * nwg + tile);
-        for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(tstamp[i], o + i);
-        __builtin_nontemporal_store((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4), o + 4);    // HW_ID
-        __builtin_nontemporal_store((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20), o + 5);   // XCC_ID
+        unsigned long long* o = g_gemm_timing + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        for (int i = 0; i < 5; ++i) __builtin_nontemporal_store(tstamp[i], o + i);
+        __builtin_nontemporal_store((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4), o + 5);    // HW_ID
+        __builtin_nontemporal_store((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20), o + 6);   // XCC_ID
     }
 #endif
-    if (tile + (int)gridDim.x < nwg) __syncthreads();  // the next tile's prologue overwrites the LDS the epilogue read
-    }
 }
 
 #ifdef DUN_GEMM_TIMING
@@ -804,12 +811,9 @@ static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream
         const size_t n4 = (size_t)p.M * p.N / 4;
         const int g = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
         hipLaunchKernelGGL(splitk_sum_kernel, dim3(g), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
-    } else if (dma) {
-        // A/B hook: DUN_GEMM_PERSIST=n launches n workgroups (a multiple of 8, e.g. 512 = two per CU) that walk the tiles
-        static const int env_persist = getenv("DUN_GEMM_PERSIST") ? atoi(getenv("DUN_GEMM_PERSIST")) : 0;
-        const int g = (env_persist >= 8 && env_persist % 8 == 0 && env_persist < grid) ? env_persist : grid;
-        hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(g), dim3(256), 0, s, p);
-    } else {
+    } else if (dma)
+        hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
+    else {
         const dim3 g2(grid, p.ksplit > 1 ? p.ksplit : 1);
         if (small && vec)
             hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 1>), g2, dim3(256), 0, s, p);

@@ -474,13 +474,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < VW; ++e) { acc[e] = 0.f; mu[e] = rs[e] = k0[e] = mg[e] = mgx[e] = 0.f; }
     if (c < W) {
+        // one fp64 division per thread, not 2*VW: a software division is ~100 instructions and eight of them were as
+        // long as the thread's whole 32-row loop (exact for power-of-two batches, one fp64 rounding otherwise)
+        const double inv_count = 1.0 / count;
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
             mu[e] = mean[c + e];
             rs[e] = rstd[c + e];
             k0[e] = gamma[c + e] * rs[e];
-            mg[e] = (float)(sums[c + e] / count);
-            mgx[e] = (float)(sums[W + c + e] / count);
+            mg[e] = (float)(sums[c + e] * inv_count);
+            mgx[e] = (float)(sums[W + c + e] * inv_count);
         }
         const int r1 = min(B, (slab + 1) * SLAB);
 #pragma unroll 4

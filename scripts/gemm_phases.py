@@ -7,14 +7,16 @@ workgroup start, first MFMA, end of the K loop and workgroup end, per workgroup,
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "dun_amd", "libdun_hip_timing.so")
+TAG = os.environ.get("DUN_TIMING_TAG", "")  # e.g. DUN_TIMING_TAG=nt DUN_TIMING_FLAGS=-DDUN_EPI_STORE_AUX=2 with --build
+LIB = os.path.join(ROOT, "dun_amd", "libdun_hip_timing%s.so" % TAG)
 
 if "--build" in sys.argv:
     from dun_amd import build as B
     B.build_library()
     objdir = os.path.join(ROOT, "dun_amd", "build")
-    o = os.path.join(objdir, "gemm_timing.o")
-    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDUN_GEMM_TIMING", "-c",
+    o = os.path.join(objdir, "gemm_timing%s.o" % TAG)
+    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-DDUN_GEMM_TIMING"] +
+                   os.environ.get("DUN_TIMING_FLAGS", "").split() + ["-c",
                     os.path.join(B.CSRC, "gemm.hip"), "-o", o], check=True)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in B.SOURCES if s != "gemm.hip"] + [o]
     subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, check=True)
@@ -39,7 +41,7 @@ R = torch.randn(M, N, device="cuda", generator=g)
 out = torch.empty(M, N, device="cuda")
 skws = torch.empty(2 * N * N, device="cuda")
 gw = torch.empty(N, N, device="cuda")
-stamps = torch.zeros(8192 * 2 * 6, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(8192 * 2 * 8, dtype=torch.int64, device="cuda")
 
 
 def run(name, fn, nwg):
@@ -52,7 +54,7 @@ def run(name, fn, nwg):
     e0.record(); fn(); e1.record()
     torch.cuda.synchronize()
     assert lib.dun_debug_gemm_timing(None) == 0
-    t = stamps.cpu().numpy().reshape(-1, 6)[:nwg].astype(np.int64)
+    t = stamps.cpu().numpy().reshape(-1, 8)[:nwg].astype(np.int64)
     ms = e0.elapsed_time(e1)
     # the counters of different XCDs are not aligned with each other: only differences inside a workgroup (and inside
     # a CU) mean anything.  Tick length: two workgroups at a time fill a CU for the whole launch.
@@ -60,12 +62,14 @@ def run(name, fn, nwg):
     tick_ns = ms * 1e6 / ((t[:, 3] - t[:, 0]).sum() / (2.0 * ncu))
     pro, loop, epi, life = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]
     print("%s: %.3f ms, %d workgroups, clock tick %.2f ns" % (name, ms, nwg, tick_ns))
-    for lab, v in (("start -> first MFMA", pro), ("K loop", loop), ("epilogue (to stores drained)", epi), ("lifetime", life)):
+    issue = t[:, 4] - t[:, 2]
+    for lab, v in (("start -> first MFMA", pro), ("K loop", loop), ("epilogue, to last instruction", issue),
+                   ("epilogue, to stores drained", epi), ("lifetime", life)):
         print("    %-30s mean %8.2f us  median %8.2f  p95 %8.2f   %.1f %% of lifetime" % (
             lab, v.mean() * tick_ns / 1e3, np.median(v) * tick_ns / 1e3, np.percentile(v, 95) * tick_ns / 1e3,
             100.0 * v.sum() / life.sum()))
     # gap between consecutive workgroups of one hardware slot: key = (xcc, se, cu, wave slot of wave 0)
-    hw, xcc = t[:, 4], t[:, 5] & 0xF
+    hw, xcc = t[:, 5], t[:, 6] & 0xF
     key = (xcc << 32) | (hw & 0xFFFFF)  # wave_id, simd, pipe, cu, sh, se, tg_id -- slot of the first wave
     cu = (xcc << 16) | ((hw >> 8) & 0xFF) | (((hw >> 13) & 7) << 8)
     gaps = []
