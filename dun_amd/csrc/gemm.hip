@@ -629,7 +629,11 @@ __device__ __forceinline__ void read_frag_half(const float* lds, int row, int t,
 // outstanding at the first MFMA of a group, one more than the 4-bit counter can express, and the compiler falls back
 // to lgkmcnt(0) THERE: the prefetch it just issued is waited for instead of hidden (dW: K loop at 0.908 of peak
 // against 0.942 for the K-contiguous images, whose four ds_read_b128 per group stay countable).
+#ifdef DUN_NO_LGKM_WAIT  // A/B build
+#define DUN_WAIT_LGKMCNT0() do { } while (0)
+#else
 #define DUN_WAIT_LGKMCNT0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#endif
 
 #ifdef DUN_GEMM_TIMING
 // Diagnostic build only (scripts/gemm_phases.py builds its own library with -DDUN_GEMM_TIMING): every workgroup of the
