@@ -204,6 +204,9 @@ class HipBackend(object):
         if y is not None and y.numel() != (act[0].numel() if regression else act.shape[1]):
             raise RuntimeError("targets (%d) do not match the batch of act_vec %s" % (y.numel(), tuple(act.shape)))
         metrics = None
+        if act.shape[1] == 0 and y is None:  # empty inference batch: empty outputs, like the reference's torch ops
+            empty = torch.empty(act.shape[1:], device=dev, dtype=torch.float32)
+            return empty, (torch.empty_like(empty) if (regression and get_std) else None), None
         if regression:
             n = act[0].numel()
             mean = torch.empty(act.shape[1:], device=dev, dtype=torch.float32)

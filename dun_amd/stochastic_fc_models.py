@@ -223,6 +223,15 @@ class arq_uncert_fc_resnet(nn.Module):
     def _run_forward(self, x, depth, train, objective=None):
         if x.dim() != 2 or x.shape[1] != self.input_dim:
             raise RuntimeError("expected x of shape [B, %d], got %s" % (self.input_dim, tuple(x.shape)))
+        if train and depth > 0:
+            # nn.BatchNorm1d in training mode (torch.nn.functional.batch_norm -> _verify_batch_size): a batch of one
+            # row has no variance.  The reference's blocks raise this from a ragged last batch of size 1; here the
+            # unbiased running-variance update would divide by n - 1 = 0 and poison the running statistics silently.
+            dist = self._dist
+            n_stat = dist.global_batch(x.shape[0]) if (dist is not None and dist.sync_bn) else x.shape[0]
+            if n_stat <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                                 % (torch.Size([x.shape[0], self.width]),))
         be = kernels.backend()
         x = x.detach().to(torch.float32).contiguous()
         buf = self._get_buffers(x.shape[0], depth, train)
@@ -308,6 +317,8 @@ class arq_uncert_fc_resnet(nn.Module):
         """act_vec [depth+1, B, O].  ``objective`` (probability.HeadObjective, regression with one output) additionally
         runs the likelihood pass inside the head kernels and leaves its results in that object."""
         depth = self.n_layers if depth is None else depth
+        if x.dim() == 2 and x.shape[0] == 0 and x.shape[1] == self.input_dim and not self.training:
+            return x.new_zeros(depth + 1, 0, self.output_dim, dtype=torch.float32)  # (no rows: nothing to launch)
         if self.training and torch.is_grad_enabled():
             return _FcForward.apply(self, x, depth, objective, *self._param_list)
         return self._run_forward(x, depth, self.training, objective).act

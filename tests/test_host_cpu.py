@@ -360,3 +360,19 @@ def test_committed_bench_line_keeps_the_driver_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     # value = global batch / step time
     assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_one_row_training_batch_raises_like_batchnorm(cpu_backend):
+    """nn.BatchNorm1d refuses a training batch of one row (the reference raises this ValueError from a ragged last
+    batch, src/DUN/layers.py:33-53 through torch.nn.functional.batch_norm); evaluation of one row is fine."""
+    c = Case("c2_boston")
+    net = build_cpu_net(c)
+    x, y = c.t("x"), c.y()
+    net.fit(x, y)
+    rv = net.model.running_var.clone()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        net.fit(x[:1], y[:1])
+    assert torch.equal(rv, net.model.running_var)  # nothing ran
+    full = net.predict(x[:4])
+    assert torch.allclose(net.predict(x[2:3]), full[2:3], rtol=1e-5, atol=1e-6)
+    assert len(net.eval(x[:1], y[:1])) == 2

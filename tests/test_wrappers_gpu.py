@@ -271,6 +271,27 @@ def test_reference_state_checkpoint_on_the_device(tmp_path):
     assert torch.equal(net.model.flat_params, other.model.flat_params)
 
 
+def test_one_row_batches():
+    """A training batch of one row raises BatchNorm's ValueError like the reference; one-row evaluation runs the
+    kernels at B = 1 and equals the same row inside a larger batch."""
+    for name in ("c2_boston", "c3_reduced", "cls_fc"):
+        c = Case(name)
+        net = build_net(c)
+        x, y = c.t("x").cuda(), c.y().cuda()
+        net.fit(x, y)
+        with pytest.raises(ValueError, match="more than 1 value per channel"):
+            net.fit(x[:1], y[:1])
+        full = net.predict(x[:5])
+        one = net.predict(x[3:4])
+        assert one.shape == full[3:4].shape
+        assert torch.allclose(one, full[3:4], rtol=2e-5, atol=1e-6), name
+        ev = net.eval(x[:1], y[:1])
+        assert all(np.isfinite(v) for v in ev), (name, ev)
+        none = net.predict(x[:0])  # an empty inference batch gives empty outputs, like the reference's torch ops
+        assert none.shape == (0,) + tuple(full.shape[1:]) and none.is_cuda
+        assert np.allclose(net.fit(x, y), c["fit/ret"][1], rtol=2e-3, atol=1e-6)  # the refused step left no trace
+
+
 def test_label_semantics_through_the_wrapper():
     from tests.test_host_cpu import check_label_semantics_through_the_wrapper
     check_label_semantics_through_the_wrapper(build_net)
