@@ -86,6 +86,25 @@ def run(name, fn, nwg):
     print("    CUs seen %d; workgroups per CU %.1f; end of a workgroup -> start of the next on the same CU: mean %.2f us  median %.2f  p95 %.2f" % (
         len(np.unique(cu)), nwg / len(np.unique(cu)), gaps.mean() * tick_ns / 1e3, np.median(gaps) * tick_ns / 1e3,
         np.percentile(gaps, 95) * tick_ns / 1e3))
+    # are the workgroups in phase?  per XCD (its counters are one clock): how many of its 64 resident workgroups sit in
+    # their epilogue at the same moment (64 * epilogue / lifetime ~ 2-3 if phases were uniform)
+    conc, conc_first = [], []
+    for x in np.unique(xcc):
+        idx = np.where(xcc == x)[0]
+        ev = sorted([(a, 1) for a in t[idx, 2]] + [(b, -1) for b in t[idx, 4]])
+        cur, series = 0, []
+        for _, d in ev:
+            cur += d
+            series.append(cur)
+        conc.append(max(series))
+        order = idx[np.argsort(t[idx, 0])]
+        per_round = len(idx) // max(1, len(idx) // 64) if len(idx) >= 64 else len(idx)
+        # spread of the start times of the LAST 64 workgroups started on this XCD (= the last round), in units of a lifetime
+        last = np.sort(t[idx, 0])[-64:] if len(idx) >= 128 else np.sort(t[idx, 0])
+        conc_first.append((last.max() - last.min()) / max(1.0, life.mean()))
+    print("    in phase?  workgroups of one XCD inside their epilogue at once: max %s of 64 resident (uniform phases would give ~%.1f); "
+          "start-time spread of an XCD's last 64 workgroups: %.2f lifetimes" % (
+              sorted(conc)[len(conc) // 2], 64.0 * issue.mean() / life.mean(), float(np.median(conc_first))))
     print("    loop share of the launch: %.3f; ideal loop time at 157.3 TF: %.2f us per workgroup (two per CU)" % (
         loop.sum() / life.sum(), 2.0 * 2 * 128 * 128 * K / (157.3e12 / 256) * 1e6 / (2 if nwg == 512 else 1)))
     sys.stdout.flush()
