@@ -514,6 +514,68 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// Row-owned form of bn_bwd_apply for the wide trunk (width = NCH*256 <= 2048, planes beyond the Infinity Cache): a
+// wavefront owns a row, like bn_apply_head_kernel, and streams 8 KB-contiguous rows instead of the 1 KB pieces at an
+// 8 KB stride that a column-owned workgroup reads.  Per-column constants in registers (k0 = gamma*rstd, mean, mean_g,
+// rstd*mean_gx: four, so that with the db accumulators and 16 loads in flight the lane stays under 256 VGPRs -- the
+// column-owned kernel keeps rstd and mean_gx apart, one rounding of difference); the bias-gradient column sums are
+// accumulated per lane over the wavefront's rows and combined over the four wavefronts through LDS in a fixed order:
+// one [W] partial per workgroup, the layout reduce_cols_kernel expects.
+template <int NCH, bool NT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const float* __restrict__ G, const float* __restrict__ Z,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma,
+                                                                const double* __restrict__ sums, double count, int B,
+                                                                float* __restrict__ dU, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) float red[4 * NCH * 256];
+    constexpr int W = NCH * 256;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    f32x4 k0[NCH], mu[NCH], mg[NCH], cx[NCH], acc[NCH];
+    const double inv_count = 1.0 / count;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        mu[j] = *reinterpret_cast<const f32x4*>(mean + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            k0[j][e] = g4[e] * rs[e];
+            mg[j][e] = (float)(sums[c + e] * inv_count);
+            cx[j][e] = rs[e] * (float)(sums[W + c + e] * inv_count);
+            acc[j][e] = 0.f;
+        }
+    }
+    for (int row = wave; row < B; row += nwaves) {
+        const size_t off = (size_t)row * W + lane * 4;
+        f32x4 g[NCH], z[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) g[j] = ld4_stream<NT>(G + off + j * 256);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) z[j] = ld4_stream<NT>(Z + off + j * 256);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            f32x4 du;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                du[e] = z[j][e] > 0.f ? k0[j][e] * ((g[j][e] - mg[j][e]) - (z[j][e] - mu[j][e]) * cx[j][e]) : 0.f;
+            st4_stream<NT>(dU + off + j * 256, du);
+            acc[j] += du;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) *reinterpret_cast<f32x4*>(red + wv * W + (j * 64 + lane) * 4) = acc[j];
+    __syncthreads();
+    float* dst = partials + (size_t)blockIdx.x * W;
+    for (int c = threadIdx.x * 4; c < W; c += 1024) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(red + c);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + w * W + c);
+        *reinterpret_cast<f32x4*>(dst + c) = t;
+    }
+}
+
 // per-slab column sums of X [B,W] -> partials [P][W]
 template <int VW, bool NT = false>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int B, int W, int SLAB,
@@ -927,7 +989,15 @@ static int bwd_block_du(const dun_fc_ctx* c, int i, double global_batch, hipStre
     const float* mean = c->bn_mean + (size_t)i * W;
     const float* rstd = c->bn_rstd + (size_t)i * W;
     const float* gamma = c->p.gamma + (size_t)i * W;
-    if (vec4_ok(W, c->G, Z, c->dU)) {
+    // A/B hook: DUN_BWD_ROWS=0 keeps the column-owned kernel at every size
+    static const bool rows_ok = !(getenv("DUN_BWD_ROWS") && getenv("DUN_BWD_ROWS")[0] == '0');
+    if (rows_ok && nt && W % 256 == 0 && W <= 2048 && vec4_ok(W, c->G, Z, c->dU) && aligned16(c->ws)) {
+        // P workgroups of four wavefronts, slab_rows/4 rows per wavefront; partials [P][W] as below
+#define BBR(N) case N: hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<N, true>), dim3(P), dim3(256), 0, s, c->G, Z, mean, rstd, \
+                                          gamma, c->bn_sums, global_batch, B, c->dU, c->ws); break;
+        switch (W / 256) { BBR(1) BBR(2) BBR(3) BBR(4) BBR(5) BBR(6) BBR(7) BBR(8) }
+#undef BBR
+    } else if (vec4_ok(W, c->G, Z, c->dU)) {
         if (nt)
             hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(ceil_div(W, CX * 4), P), dim3(256), 0, s, c->G, Z, mean,
                                rstd, gamma, c->bn_sums, global_batch, B, W, slab_rows_for(B), c->dU, c->ws);
