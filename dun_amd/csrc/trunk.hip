@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256) void reduce_cols_kernel(const PT* __restrict__
     double s = 0.0;
     if (c < W) {
         const PT* src = partials + (size_t)a * P * W + c;
+        // (unrolled: the loads of eight steps go out together; the additions keep their order -- as a rolled loop the
+        // P/16 steps were a chain of cache round trips, 16 us for the 512 row tiles of the wide trunk)
+#pragma unroll 8
         for (int p = ty; p < P; p += RCY) s += (double)src[(size_t)p * W];
     }
     red[ty][tx] = s;
@@ -118,6 +121,8 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* _
     if (c < W) {
         const double* a1 = partials + c;
         const double* a2 = partials + (size_t)P * W + c;
+        // (in-step at the wide configuration, same box: rolled 17.1 us, unrolled by 4: 8.1 us, by 8: 22.7 us)
+#pragma unroll 4
         for (int p = ty; p < P; p += RCY) {
             s1 += a1[(size_t)p * W];
             s2 += a2[(size_t)p * W];
