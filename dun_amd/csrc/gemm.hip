@@ -55,6 +55,7 @@ struct GemmP {
     float* part;  // [ksplit][M][N]
     int gm;       // LDS-DMA kernel: row panels per tile group (1: tiles of one row panel are consecutive)
     int rinit;    // LDS-DMA kernel: accumulators start from R (loaded under the pipeline prologue), not added at the end
+    int wide;     // 128 x 256 tiles (gemm_f32_wide_kernel): gridN counts 256-column tiles
 };
 
 // ---- global -> register staging of one operand tile: 4 x float4 per thread ----
@@ -136,9 +137,9 @@ __device__ __forceinline__ void read_frag(const float* lds, int row, int t, int 
 // ((4h*ld + wc*WT + li)*4, + ni*128 as an immediate) and the row part ((m0 + wr*WT + mi*32 + (r&3) + 8(r>>2))*ld + n0)*4
 // as a SCALAR offset -- with flat addresses the 64 loads + 64 stores of an epilogue held a 64-bit address each and
 // the epilogue spilled.  Ragged tiles (register-staged kernels) use bounds-checked flat accesses.
-template <bool FULL, int MI>
+template <bool FULL, int MI, int NI = MI>
 struct TileIO {
-    static constexpr int WT = 32 * MI;
+    static constexpr int WT = 32 * MI, WTN = 32 * NI;  // rows / columns of a wave's sub-tile
     __amdgpu_buffer_rsrc_t rs;
     const float* base;
     int ld, voff, M, N, m0w, n0, colw, h;
@@ -148,7 +149,7 @@ struct TileIO {
         base = ptr; ld = ld_; M = p.M; N = p.N; h = h_;
         m0w = m0 + wr * WT;        // wave-uniform on the FULL path (wr comes from a readfirstlane)
         n0 = n0_;
-        colw = wc * WT + li;
+        colw = wc * WTN + li;
         if (FULL) {
             rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)((((long long)p.M - 1) * ld + p.N) * 4),
                                                    0x00020000);
@@ -176,63 +177,65 @@ struct TileIO {
 
 // C = R + A B with the accumulators STARTING from the R tile: its loads go out in front of the operand pipeline's
 // prologue and land under it, instead of a dependent HBM round trip in the epilogue behind an empty matrix pipe.
-template <bool FULL, int MI>
-__device__ __forceinline__ void seed_acc(const GemmP& p, f32x16 (&acc)[MI][MI], int m0, int n0, int wr, int wc, int li,
+template <bool FULL, int MI, int NI = MI>
+__device__ __forceinline__ void seed_acc(const GemmP& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wr, int wc, int li,
                                          int h) {
     if (p.rinit) {
-        const TileIO<FULL, MI> R(p.R, p.ldr, p, m0, n0, wr, wc, li, h);
+        const TileIO<FULL, MI, NI> R(p.R, p.ldr, p, m0, n0, wr, wc, li, h);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < MI; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = R.load(mi, ni, r);
     } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < MI; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     }
 }
 
 // ---- epilogue shared by all kernels.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// A wave owns MI x NI accumulators (32*MI rows, 32*NI columns); the four waves are 2 x 2.
 // FULL: the tile lies completely inside C (no bounds checks).
 // BNS: the launch takes the BatchNorm backward statistics (GemmP::bnz) -- then there is no bias / ReLU / residual /
 // forward statistics in the epilogue (host-checked), and the two forms are compiled apart so that neither carries the
 // other's registers.
-template <bool FULL, int MI, bool BNS>
-__device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, f32x16 (&acc)[MI][MI], float* smem, int m0, int n0,
+// LEAN (the wide kernel, 128 accumulator registers): no residual gather (the host only sends residuals that seed the
+// accumulators) and no rank update here -- the kernel adds the rank-1 term u v^T as one more MFMA step per accumulator
+// (holding the 32 row values of u next to 128 accumulators and a Z tile made the register allocator spill).
+template <bool FULL, int MI, int NI, bool BNS, bool LEAN = false>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, f32x16 (&acc)[MI][NI], float* smem, int m0, int n0,
                                                    int bm, int tid, int wave, int wr, int wc, int li, int h) {
-    constexpr int WT = 32 * MI;  // wave sub-tile edge
+    constexpr int WTN = 32 * NI;  // columns of a wave's sub-tile
+    // Columns are worked through in chunks of NC accumulator columns: the addend tile of a chunk (residual, or the Z
+    // tile of the BatchNorm statistics) is gathered into MI*NC*16 registers before the chunk's stores.  Square wave
+    // tiles are one chunk; the 2 x 4 tile of the wide kernel takes two (all four at once would be 128 registers next to
+    // 128 accumulators).
+    constexpr int NC = NI > 2 ? 2 : NI;
     // BatchNorm statistics are accumulated in fp64 from the first element on: sum z^2 - (sum z)^2/n in fp32
     // loses the variance of a nearly constant column (narrow inputs make many of those), and the reference's
     // batch_norm uses a cancellation-free update.  64 dfma per lane per tile: free next to the K loop.
-    double s1[MI], s2[MI];
+    double s1[NI], s2[NI];
 #pragma unroll
-    for (int ni = 0; ni < MI; ++ni) s1[ni] = s2[ni] = 0.0;
+    for (int ni = 0; ni < NI; ++ni) s1[ni] = s2[ni] = 0.0;
     // Addends first, stores later.  R may BE C (the running gradient is updated in place), so the compiler cannot
     // move a residual load above an earlier store of this thread and would pay one HBM round trip per element; every
     // element is read and written by its own thread only, so gathering all of them up front is safe.
     // The residual tile and the Z tile of the BatchNorm statistics share one register array: a launch has one or the
     // other in its epilogue (the trunk's dX GEMM seeds its accumulators with the residual instead, `rinit`).
     constexpr bool has_bn = BNS;
-    const bool has_r = !BNS && p.R != nullptr && !p.rinit, has_u1 = p.U != nullptr && p.O == 1;
-    const TileIO<FULL, MI> Cio(p.C, p.ldc, p, m0, n0, wr, wc, li, h);
-    float aux[MI][MI][16], uu[MI][16], sg[MI], sgx[MI];
+    const bool has_r = !BNS && !LEAN && p.R != nullptr && !p.rinit;
+    const bool has_u1 = !LEAN && p.U != nullptr && p.O == 1;
+    const TileIO<FULL, MI, NI> Cio(p.C, p.ldc, p, m0, n0, wr, wc, li, h);
+    const TileIO<FULL, MI, NI> Aio(has_bn ? p.bnz : p.R, has_bn ? p.ldz : p.ldr, p, m0, n0, wr, wc, li, h);
+    float uu[LEAN ? 1 : MI][16], sg[NI], sgx[NI];  // LEAN: the row values of one mi at a time (see below)
 #pragma unroll
-    for (int ni = 0; ni < MI; ++ni) sg[ni] = sgx[ni] = 0.f;
-    if (has_r || has_bn) {
-        const TileIO<FULL, MI> Aio(has_bn ? p.bnz : p.R, has_bn ? p.ldz : p.ldr, p, m0, n0, wr, wc, li, h);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < MI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) aux[mi][ni][r] = Aio.load(mi, ni, r);
-    }
-    if (has_u1) {
+    for (int ni = 0; ni < NI; ++ni) sg[ni] = sgx[ni] = 0.f;
+    if (has_u1 && !LEAN) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -242,87 +245,112 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, f32x16 (&acc)
             }
     }
 #pragma unroll
-    for (int ni = 0; ni < MI; ++ni) {
-        const int col = n0 + wc * WT + ni * 32 + li;
-        const bool col_ok = FULL || col < p.N;
-        const float bv = (!BNS && p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
-        const float v1 = (has_u1 && col_ok) ? p.V[col] : 0.f;
-        const float bmu = (has_bn && col_ok) ? p.bn_mean[col] : 0.f;
-        const float brs = (has_bn && col_ok) ? p.bn_rstd[col] : 0.f;
+    for (int n0c = 0; n0c < NI; n0c += NC) {
+        float aux[MI][NC][16];
+        if (has_r || has_bn) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) aux[mi][nc][r] = Aio.load(mi, n0c + nc, r);
+        }
+        float bv[NC], v1[NC], bmu[NC], brs[NC];
+#pragma unroll
+        for (int nc = 0; nc < NC; ++nc) {
+            const int col = n0 + wc * WTN + (n0c + nc) * 32 + li;
+            const bool col_ok = FULL || col < p.N;
+            bv[nc] = (!BNS && p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+            v1[nc] = (has_u1 && col_ok) ? p.V[col] : 0.f;
+            bmu[nc] = (has_bn && col_ok) ? p.bn_mean[col] : 0.f;
+            brs[nc] = (has_bn && col_ok) ? p.bn_rstd[col] : 0.f;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+            if (LEAN && has_u1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (Cio.inside(mi, ni, r)) {
-                    float v = acc[mi][ni][r] + bv;
-                    if (!BNS && p.relu) v = v > 0.f ? v : 0.f;
-                    if (has_r) v += aux[mi][ni][r];
-                    if (has_u1) {
-                        v += uu[mi][r] * v1;
-                    } else if (!BNS && p.U != nullptr) {  // (rank-O with the statistics epilogue: refused on the host)
-                        const int row = Cio.rowu(mi, r) + 4 * h;
-                        for (int o = 0; o < p.O; ++o) v += p.U[(size_t)row * p.O + o] * p.V[(size_t)o * p.ldv + col];
-                    }
-                    Cio.store(mi, ni, r, v);
-                    if (has_bn) {
-                        sg[ni] += v;
-                        sgx[ni] += v * ((aux[mi][ni][r] - bmu) * brs);
-                    }
-                    if (!BNS && p.colstats != nullptr) {
-                        const double dv = (double)v;
-                        s1[ni] += dv;
-                        s2[ni] += dv * dv;
+                for (int r = 0; r < 16; ++r) uu[0][r] = p.U[Cio.rowu(mi, r) + 4 * h];
+            }
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) {
+                const int ni = n0c + nc;
+                const int col = n0 + wc * WTN + ni * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (Cio.inside(mi, ni, r)) {
+                        float v = acc[mi][ni][r] + bv[nc];
+                        if (!BNS && p.relu) v = v > 0.f ? v : 0.f;
+                        if (has_r) v += aux[mi][nc][r];
+                        if (has_u1) {
+                            v += uu[LEAN ? 0 : mi][r] * v1[nc];
+                        } else if (!BNS && !LEAN && p.U != nullptr) {  // (rank-O with the statistics epilogue: refused on the host)
+                            const int row = Cio.rowu(mi, r) + 4 * h;
+                            for (int o = 0; o < p.O; ++o) v += p.U[(size_t)row * p.O + o] * p.V[(size_t)o * p.ldv + col];
+                        }
+                        Cio.store(mi, ni, r, v);
+                        if (has_bn) {
+                            sg[ni] += v;
+                            sgx[ni] += v * ((aux[mi][nc][r] - bmu[nc]) * brs[nc]);
+                        }
+                        if (!BNS && p.colstats != nullptr) {
+                            const double dv = (double)v;
+                            s1[ni] += dv;
+                            s2[ni] += dv * dv;
+                        }
                     }
                 }
+                // (next to 128 accumulators the scheduler must not interleave the 16-element groups: it would hold
+                // every group's temporaries at once and spill)
+                if (LEAN) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
     if (has_bn) {
-        // 32 rows per lane (fp32, as the column-owned reduction kernel sums 32 rows per thread), the two lane halves,
-        // then the two wave rows through LDS: one partial per 128-row (64-row) tile, fixed order
+        // 32*MI rows per lane pair (fp32, as the column-owned reduction kernel sums 32 rows per thread), the two lane
+        // halves, then the two wave rows through LDS: one partial per row tile, fixed order
         float* redf = smem;  // all waves are past the last barrier: LDS is free
 #pragma unroll
-        for (int ni = 0; ni < MI; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             sg[ni] += __shfl_xor(sg[ni], 32, 64);
             sgx[ni] += __shfl_xor(sgx[ni], 32, 64);
             if (h == 0) {
-                redf[((wave * MI + ni) * 32 + li) * 2 + 0] = sg[ni];
-                redf[((wave * MI + ni) * 32 + li) * 2 + 1] = sgx[ni];
+                redf[((wave * NI + ni) * 32 + li) * 2 + 0] = sg[ni];
+                redf[((wave * NI + ni) * 32 + li) * 2 + 1] = sgx[ni];
             }
         }
         __syncthreads();
-        if (tid < 2 * WT) {
-            const int wc2 = tid / WT, ni2 = (tid / 32) % MI, l2 = tid & 31, col = n0 + tid;
+        if (tid < 2 * WTN) {
+            const int wc2 = tid / WTN, ni2 = (tid / 32) % NI, l2 = tid & 31, col = n0 + tid;
             if (FULL || col < p.N) {
                 const int w0 = wc2, w1 = 2 + wc2;  // wave rows 0 and 1 of this wave column
                 p.bnstats[(size_t)bm * p.N + col] =
-                    redf[((w0 * MI + ni2) * 32 + l2) * 2 + 0] + redf[((w1 * MI + ni2) * 32 + l2) * 2 + 0];
+                    redf[((w0 * NI + ni2) * 32 + l2) * 2 + 0] + redf[((w1 * NI + ni2) * 32 + l2) * 2 + 0];
                 p.bnstats[(size_t)(p.gridM + bm) * p.N + col] =
-                    redf[((w0 * MI + ni2) * 32 + l2) * 2 + 1] + redf[((w1 * MI + ni2) * 32 + l2) * 2 + 1];
+                    redf[((w0 * NI + ni2) * 32 + l2) * 2 + 1] + redf[((w1 * NI + ni2) * 32 + l2) * 2 + 1];
             }
         }
     }
     if (!BNS && p.colstats != nullptr) {
         double* red = reinterpret_cast<double*>(smem);  // all waves are past the last barrier: LDS is free
 #pragma unroll
-        for (int ni = 0; ni < MI; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             s1[ni] += __shfl_xor(s1[ni], 32, 64);
             s2[ni] += __shfl_xor(s2[ni], 32, 64);
             if (h == 0) {
-                red[((wave * MI + ni) * 32 + li) * 2 + 0] = s1[ni];
-                red[((wave * MI + ni) * 32 + li) * 2 + 1] = s2[ni];
+                red[((wave * NI + ni) * 32 + li) * 2 + 0] = s1[ni];
+                red[((wave * NI + ni) * 32 + li) * 2 + 1] = s2[ni];
             }
         }
         __syncthreads();
-        if (tid < 2 * WT) {
-            const int wc2 = tid / WT, ni2 = (tid / 32) % MI, l2 = tid & 31, col = n0 + tid;
+        if (tid < 2 * WTN) {
+            const int wc2 = tid / WTN, ni2 = (tid / 32) % NI, l2 = tid & 31, col = n0 + tid;
             if (FULL || col < p.N) {
                 double t1 = 0.0, t2 = 0.0;
 #pragma unroll
                 for (int w2 = 0; w2 < 2; ++w2) {
                     const int wv = w2 * 2 + wc2;
-                    t1 += red[((wv * MI + ni2) * 32 + l2) * 2 + 0];
-                    t2 += red[((wv * MI + ni2) * 32 + l2) * 2 + 1];
+                    t1 += red[((wv * NI + ni2) * 32 + l2) * 2 + 0];
+                    t2 += red[((wv * NI + ni2) * 32 + l2) * 2 + 1];
                 }
                 p.colstats[(size_t)bm * p.N + col] = t1;
                 p.colstats[(size_t)(p.gridM + bm) * p.N + col] = t2;
@@ -331,13 +359,13 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, f32x16 (&acc)
     }
 }
 
-template <bool FULL, int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][MI], float* smem, int m0, int n0, int bm,
+template <bool FULL, int MI, int NI = MI, bool LEAN = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MI][NI], float* smem, int m0, int n0, int bm,
                                               int tid, int wave, int wr, int wc, int li, int h) {
     if (p.bnz != nullptr)
-        gemm_epilogue_impl<FULL, MI, true>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+        gemm_epilogue_impl<FULL, MI, NI, true, LEAN>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
     else
-        gemm_epilogue_impl<FULL, MI, false>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+        gemm_epilogue_impl<FULL, MI, NI, false, LEAN>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
 }
 
 // MI = MFMA tiles per wave and dimension: 2 -> 128x128 workgroup tile, 1 -> 64x64 (problems too small to fill the
@@ -783,6 +811,178 @@ extern "C" int dun_debug_gemm_timing(void* buf) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------
+// Wide variant: 128 x 256 tiles (a wave owns 64 x 128 = 2 x 4 MFMA accumulators), three 16-deep stages of 24 KiB
+// (72 KiB: still two workgroups per CU).  Per barrier a wave now issues 64 MFMAs instead of 32 and reads 12 fragment
+// vectors instead of 8, and a tile's prologue / store bubble is paid once per 2x the work.  With three stages the DMA
+// runs one half tile ahead (issued at the midpoint of half j for half j+2, into the stage half j-1 just left); a
+// half tile is 64 MFMAs per wave (~3.5 us with two waves per SIMD), more than an HBM round trip.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int WBN = 256;
+constexpr int WA_HALF = BM * HK, WB_HALF = WBN * HK;  // floats per operand image
+constexpr int WSTAGE = WA_HALF + WB_HALF;
+
+template <bool KC, int ROWS>
+struct DmaOpW {
+    static constexpr int NP = ROWS / 64;  // 1 KiB pieces per wave and half tile
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[NP];
+    int kstep;
+    __device__ __forceinline__ void setup(const float* P, int ld, int r0, int rows, int K, int wave, int lane) {
+        const long long extent = KC ? ((long long)(rows - 1) * ld + K) * 4 : ((long long)(K - 1) * ld + rows) * 4;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, (int)extent, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int piece = wave * NP + j;
+            if (KC) {  // image [ROWS][16], 16-byte chunk index XOR (row >> 2) & 3
+                const int row = piece * 16 + (lane >> 2), pc = lane & 3;
+                const int c = pc ^ ((row >> DUN_KC_SWZ_SHIFT) & 3);
+                voff[j] = ((r0 + row) * ld + c * 4) * 4;
+            } else if (ROWS == 128) {  // image [16][128]: a piece is two k rows
+                const int k = piece * 2 + (lane >> 5), col = (lane & 31) * 4;
+                voff[j] = (k * ld + r0 + col) * 4;
+            } else {  // image [16][256]: a piece is one k row
+                voff[j] = (piece * ld + r0 + lane * 4) * 4;
+            }
+        }
+        kstep = KC ? 4 : ld * 4;
+    }
+    __device__ __forceinline__ void issue(int k0, float* lds, int wave) const {
+        const int soff = k0 * kstep;
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + (wave * NP + j) * 256),
+                                                     16, voff[j], soff, 0, 0);
+    }
+};
+
+template <bool KC, int ROWS>
+__device__ __forceinline__ void read_frag_w(const float* lds, int row, int t, int h, float (&f)[4]) {
+    if (KC) {
+        const int pc = (2 * t + h) ^ ((row >> DUN_KC_SWZ_SHIFT) & 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * HK + pc * 4);
+        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = lds[(8 * t + 4 * h + e) * ROWS + row];
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) float smem[3 * WSTAGE];
+    const int nwg = p.gridM * p.gridN;  // gridN counts 256-column tiles here
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.gridN, bn = bid % p.gridN;
+    const int m0 = bm * BM, n0 = bn * WBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][4];
+    seed_acc<true, 2, 4>(p, acc, m0, n0, wr, wc, li, h);
+
+    const int kbeg = 0;          // (no split-K here: the host sends problems that fill the chip with whole tiles)
+    const int nh = p.K / HK;     // >= 2
+    DmaOpW<A_KC, BM> dA;
+    DmaOpW<B_KC, WBN> dB;
+    dA.setup(p.A, p.lda, m0, p.M, p.K, wave, lane);
+    dB.setup(p.B, p.ldb, n0, p.N, p.K, wave, lane);
+    // prologue: halves 0 and 1 in flight (2 + 4 DMA instructions per half and wave), half 0 landed and visible
+    dA.issue(kbeg, smem, wave);
+    dB.issue(kbeg, smem + WA_HALF, wave);
+    dA.issue(kbeg + HK, smem + WSTAGE, wave);
+    dB.issue(kbeg + HK, smem + WSTAGE + WA_HALF, wave);
+    DUN_WAIT_VMCNT(6);
+    __builtin_amdgcn_s_barrier();
+    // (kernel arguments of the epilogue into SGPRs before the loop: see gemm_f32_dma4_kernel)
+    asm volatile("" ::"s"(p.C), "s"(p.bias), "s"(p.R), "s"(p.U), "s"(p.V), "s"(p.colstats), "s"(p.M), "s"(p.N),
+                 "s"(p.ldc), "s"(p.ldr), "s"(p.O), "s"(p.ldv), "s"(p.relu), "s"(p.gridM), "s"(p.rinit), "s"(p.bnz),
+                 "s"(p.bn_mean), "s"(p.bn_rstd), "s"(p.bnstats), "s"(p.ldz));
+
+    float fa[2][2][4], fb[2][4][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) read_frag_w<A_KC, BM>(smem, wr * 64 + mi * 32 + li, 0, h, fa[0][mi]);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) read_frag_w<B_KC, WBN>(smem + WA_HALF, wc * 128 + ni * 32 + li, 0, h, fb[0][ni]);
+    DUN_WAIT_LGKMCNT0();
+
+    int cur = 0, nxt = WSTAGE, iss = 2 * WSTAGE;  // float offsets of the stages of half j, j+1, j+2
+#define DUN_WIDE_STEP(J, NEXT, ISSUE)                                                                                  \
+    do {                                                                                                               \
+        const float* a_s = smem + cur;                                                                                 \
+        const float* b_s = a_s + WA_HALF;                                                                              \
+        _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                               \
+            read_frag_w<A_KC, BM>(a_s, wr * 64 + mi * 32 + li, 1, h, fa[1][mi]);                                       \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                               \
+            read_frag_w<B_KC, WBN>(b_s, wc * 128 + ni * 32 + li, 1, h, fb[1][ni]);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                       \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][mi][e], fb[0][ni][e], acc[mi][ni], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_WAIT_LGKMCNT0();                                                                                           \
+        if (NEXT) {                                                                                                    \
+            DUN_WAIT_VMCNT(0);                                                                                         \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            if (ISSUE) {                                                                                               \
+                dA.issue(kbeg + ((J) + 2) * HK, smem + iss, wave);                                                     \
+                dB.issue(kbeg + ((J) + 2) * HK, smem + iss + WA_HALF, wave);                                           \
+            }                                                                                                          \
+            const float* a_n = smem + nxt;                                                                             \
+            const float* b_n = a_n + WA_HALF;                                                                          \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+                read_frag_w<A_KC, BM>(a_n, wr * 64 + mi * 32 + li, 0, h, fa[0][mi]);                                   \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                           \
+                read_frag_w<B_KC, WBN>(b_n, wc * 128 + ni * 32 + li, 0, h, fb[0][ni]);                                 \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                       \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][mi][e], fb[1][ni][e], acc[mi][ni], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_WAIT_LGKMCNT0();                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        { const int t_ = cur; cur = nxt; nxt = iss; iss = t_; }                                                        \
+    } while (0)
+
+    int j = 0;
+    for (; j + 2 < nh; ++j) DUN_WIDE_STEP(j, true, true);
+    if (j + 1 < nh) { DUN_WIDE_STEP(j, true, false); ++j; }
+    DUN_WIDE_STEP(j, false, false);
+#undef DUN_WIDE_STEP
+
+    // rank-1 term of the head (C += u v^T, one output; host: never together with bias / ReLU): one more k step with
+    // A column u and B row v in the k = 0 half of the lanes, zeros in the other -- acc + u*v per element, like the
+    // epilogue of the other kernels computes it
+    if (p.U != nullptr) {
+        float ua[2], vb[4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) ua[mi] = h == 0 ? p.U[m0 + wr * 64 + mi * 32 + li] : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) vb[ni] = h == 0 ? p.V[n0 + wc * 128 + ni * 32 + li] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[mi], vb[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();  // the epilogue reuses the LDS for the column statistics
+    gemm_epilogue<true, 2, 4, true>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+}
+
+// (explicit instantiations: the host pass emitted the launch stub of <true, true> only)
+template __global__ void gemm_f32_wide_kernel<true, true>(const GemmP);
+template __global__ void gemm_f32_wide_kernel<true, false>(const GemmP);
+template __global__ void gemm_f32_wide_kernel<false, true>(const GemmP);
+template __global__ void gemm_f32_wide_kernel<false, false>(const GemmP);
+
 // C[m][n] = part[0][m][n] + part[1][m][n] + ... (fixed order: reproducible)
 __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ part, int ksplit, int M, int N,
                                                          float* __restrict__ C, int ldc) {
@@ -807,7 +1007,15 @@ static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream
     // the four-stage kernel addresses its operands with 32-bit byte offsets from their bases
     const bool fits32 = (long long)(A_KC ? p.M : p.K) * p.lda * 4 < (1ll << 31) &&
                         (long long)(B_KC ? p.N : p.K) * p.ldb * 4 < (1ll << 31);
-    if (dma && (g_dma_two_buffer || !fits32))
+    if (p.wide) {
+        hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+        if (p.ksplit > 1) {
+            DUN_LAUNCH_CHECK();
+            const size_t n4 = (size_t)p.M * p.N / 4;
+            const int g = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3(g), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
+        }
+    } else if (dma && (g_dma_two_buffer || !fits32))
         hipLaunchKernelGGL((gemm_f32_dma_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
     else if (dma && p.ksplit > 1) {
         hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
@@ -874,6 +1082,7 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
                 "dun_gemm_f32: bnz needs bn_mean, bn_rstd, bnstats and ldz >= N");
     p.gm = 1;
     p.rinit = 0;
+    p.wide = 0;
     const bool small = small_problem(d->M, d->N);
     const int tile = small ? 64 : BM;
     p.gridM = ceil_div(d->M, tile);
@@ -927,6 +1136,18 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
             return DUN_ERR_UNSUPPORTED;
         }
         p.rinit = (can_seed && (env_rinit || d->bnz)) ? 1 : 0;  // (the statistics epilogue shares the residual's registers)
+    }
+    {
+        // 128 x 256 tiles where they fill the chip without split-K (the trunk's forward and dX GEMMs): the per-tile
+        // prologue / store bubble is paid once per twice the work.  DUN_GEMM_WIDE=0 keeps 128 x 128 tiles.
+        static const int env_wide = getenv("DUN_GEMM_WIDE") ? atoi(getenv("DUN_GEMM_WIDE")) : 0;  // (off until measured)
+        if (env_wide && dma && fits32 && !g_dma_two_buffer && p.ksplit == 1 && d->N % WBN == 0 &&
+            (long long)p.gridM * (d->N / WBN) >= 512 && (!d->R || p.rinit) &&
+            (!d->U || (d->O == 1 && !d->bias && !d->relu)) &&
+            (d->a_kcontig || !d->b_kcontig)) {  // (the <M-contiguous, K-contiguous> instantiation spills: none of the trunk's GEMMs)
+            p.wide = 1;
+            p.gridN = d->N / WBN;
+        }
     }
     if (d->a_kcontig) {
         if (d->b_kcontig) return launch_gemm<true, true>(p, vec, dma, small, s);

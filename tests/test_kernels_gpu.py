@@ -121,6 +121,36 @@ def test_gemm_batchnorm_backward_statistics_epilogue(be, M, N, K):
     assert rel_err(s[1], (ref * xh).sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize("a_kc", [True, False])
+@pytest.mark.parametrize("b_kc", [True, False])
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 96), (16384, 1024, 32), (4096, 4096, 160)])
+def test_gemm_wide_tiles(be, M, N, K, a_kc, b_kc):
+    """Problems of at least 512 whole 128 x 256 tiles without split-K take the wide kernel (the trunk's forward GEMM
+    and the epilogue-free dX of block 0): plain result in all four layouts, the block-forward epilogue (bias, ReLU, fp64
+    column statistics per 128-row tile), and a residual that seeds the accumulators + the rank-1 head term."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A, Bw = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    A_st = dev(A if a_kc else A.t().contiguous())
+    B_st = dev(Bw if b_kc else Bw.t().contiguous())
+    core = A.double() @ Bw.double().t()
+    bound = (A.abs().double() @ Bw.abs().double().t()).max().item()
+    C = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc)
+    assert (C.cpu().double() - core).abs().max().item() <= 4e-7 * bound
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    U, V = torch.randn(M, 1, generator=g), torch.randn(1, N, generator=g)
+    Z, st = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc, bias=dev(bias), relu=True, colstats=True)
+    zref = torch.relu(core + bias.double())
+    assert (Z.cpu().double() - zref).abs().max().item() <= 4e-7 * (bound + bias.abs().max().item())
+    assert st.shape[1] == M // 128
+    s = st.cpu().double()
+    tiles = zref.view(M // 128, 128, N)
+    assert rel_err(s[0], tiles.sum(1)) < 1e-6 and rel_err(s[1], (tiles ** 2).sum(1)) < 1e-6
+    Rd = dev(R.clone())
+    out = be.gemm(A_st, B_st, M, N, K, a_kcontig=a_kc, b_kcontig=b_kc, R=Rd, U=dev(U), V=dev(V), out=Rd)
+    ref = core + R.double() + U.double() @ V.double()
+    assert (out.cpu().double() - ref).abs().max().item() <= 4e-7 * (bound + 40.0)
+
+
 # ------------------------------------------------------------------------------------------------------
 # probability module
 # ------------------------------------------------------------------------------------------------------
