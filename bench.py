@@ -170,10 +170,14 @@ def timed(fn, n, stream_sync=True, settle_ms=60.0):
     return e0.elapsed_time(e1) / n
 
 
-def gemm_kernel_name(M, N, K, a_kc, b_kc):
+def gemm_kernel_name(M, N, K, a_kc, b_kc, plain_few_tiles=False):
     """Which GEMM kernel the library dispatches for this shape (dun_amd/csrc/gemm.hip: gemm_f32)."""
     small = ((M + 127) // 128) * ((N + 127) // 128) < 128
     if not small and M % 128 == 0 and N % 128 == 0 and K % 32 == 0:
+        wide = (os.environ.get("DUN_GEMM_WIDE", "1")[:1] != "0" and N % 256 == 0 and (M // 128) * (N // 256) >= 512
+                and not plain_few_tiles and (a_kc or not b_kc))
+        if wide:
+            return "gemm_f32_wide_kernel<A_KC=%d,B_KC=%d> (128x256 tiles)" % (a_kc, b_kc)
         return "gemm_f32_dma4_kernel<A_KC=%d,B_KC=%d>" % (a_kc, b_kc)
     mi = 1 if small else 2
     return "gemm_f32_kernel<A_KC=%d,B_KC=%d,MI=%d> (%dx%d tiles)" % (a_kc, b_kc, mi, 64 * mi, 64 * mi)

@@ -814,9 +814,11 @@ extern "C" int dun_debug_gemm_timing(void* buf) {
 // ---------------------------------------------------------------------------------------------------------
 // Wide variant: 128 x 256 tiles (a wave owns 64 x 128 = 2 x 4 MFMA accumulators), three 16-deep stages of 24 KiB
 // (72 KiB: still two workgroups per CU).  Per barrier a wave now issues 64 MFMAs instead of 32 and reads 12 fragment
-// vectors instead of 8, and a tile's prologue / store bubble is paid once per 2x the work.  With three stages the DMA
-// runs one half tile ahead (issued at the midpoint of half j for half j+2, into the stage half j-1 just left); a
-// half tile is 64 MFMAs per wave (~3.5 us with two waves per SIMD), more than an HBM round trip.
+// vectors instead of 8, and a tile's prologue / store bubble is paid once per 2x the work.  Three stages carry the same
+// prefetch distance as the four of the kernel above: the last fragment of half j is read at the TOP of step j and
+// waited for (lgkmcnt) in front of the midpoint barrier, so behind that barrier the stage of half j itself is free and
+// takes half j+3, while half j+2 stays in flight.  (First version: half j+2 into the stage of half j-1, waited for one
+// step later with vmcnt(0) -- a tenth of the wave cycles waiting on memory, SQ_WAIT_ANY 0.10 against 0.04.)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int WBN = 256;
 constexpr int WA_HALF = BM * HK, WB_HALF = WBN * HK;  // floats per operand image
@@ -892,12 +894,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
     DmaOpW<B_KC, WBN> dB;
     dA.setup(p.A, p.lda, m0, p.M, p.K, wave, lane);
     dB.setup(p.B, p.ldb, n0, p.N, p.K, wave, lane);
-    // prologue: halves 0 and 1 in flight (2 + 4 DMA instructions per half and wave), half 0 landed and visible
-    dA.issue(kbeg, smem, wave);
-    dB.issue(kbeg, smem + WA_HALF, wave);
-    dA.issue(kbeg + HK, smem + WSTAGE, wave);
-    dB.issue(kbeg + HK, smem + WSTAGE + WA_HALF, wave);
-    DUN_WAIT_VMCNT(6);
+    // prologue: halves 0..2 in flight (2 + 4 DMA instructions per half and wave), half 0 landed and visible (nh >= 4)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        dA.issue(kbeg + j * HK, smem + j * WSTAGE, wave);
+        dB.issue(kbeg + j * HK, smem + j * WSTAGE + WA_HALF, wave);
+    }
+    DUN_WAIT_VMCNT(12);
     __builtin_amdgcn_s_barrier();
     // (kernel arguments of the epilogue into SGPRs before the loop: see gemm_f32_dma4_kernel)
     asm volatile("" ::"s"(p.C), "s"(p.bias), "s"(p.R), "s"(p.U), "s"(p.V), "s"(p.colstats), "s"(p.M), "s"(p.N),
@@ -911,8 +914,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
     for (int ni = 0; ni < 4; ++ni) read_frag_w<B_KC, WBN>(smem + WA_HALF, wc * 128 + ni * 32 + li, 0, h, fb[0][ni]);
     DUN_WAIT_LGKMCNT0();
 
-    int cur = 0, nxt = WSTAGE, iss = 2 * WSTAGE;  // float offsets of the stages of half j, j+1, j+2
-#define DUN_WIDE_STEP(J, NEXT, ISSUE)                                                                                  \
+    int cur = 0, nxt = WSTAGE, iss = 2 * WSTAGE;  // float offsets of the stages of half j, j+1, j+2 (a ring of three)
+#define DUN_WIDE_STEP(J, NEXT, INFLIGHT, ISSUE)                                                                                 \
     do {                                                                                                               \
         const float* a_s = smem + cur;                                                                                 \
         const float* b_s = a_s + WA_HALF;                                                                              \
@@ -928,11 +931,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         DUN_WAIT_LGKMCNT0();                                                                                           \
         if (NEXT) {                                                                                                    \
-            DUN_WAIT_VMCNT(0);                                                                                         \
+            if (INFLIGHT) DUN_WAIT_VMCNT(6); else DUN_WAIT_VMCNT(0); /* half J+1 landed, J+2 may stay in flight */     \
             __builtin_amdgcn_s_barrier();                                                                              \
-            if (ISSUE) {                                                                                               \
-                dA.issue(kbeg + ((J) + 2) * HK, smem + iss, wave);                                                     \
-                dB.issue(kbeg + ((J) + 2) * HK, smem + iss + WA_HALF, wave);                                           \
+            if (ISSUE) { /* every wave has read the last fragment of half J: its stage takes half J+3 */             \
+                dA.issue(kbeg + ((J) + 3) * HK, smem + cur, wave);                                                     \
+                dB.issue(kbeg + ((J) + 3) * HK, smem + cur + WA_HALF, wave);                                           \
             }                                                                                                          \
             const float* a_n = smem + nxt;                                                                             \
             const float* b_n = a_n + WA_HALF;                                                                          \
@@ -953,9 +956,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
     } while (0)
 
     int j = 0;
-    for (; j + 2 < nh; ++j) DUN_WIDE_STEP(j, true, true);
-    if (j + 1 < nh) { DUN_WIDE_STEP(j, true, false); ++j; }
-    DUN_WIDE_STEP(j, false, false);
+    for (; j + 3 < nh; ++j) DUN_WIDE_STEP(j, true, true, true);    // steady state
+    { DUN_WIDE_STEP(j, true, true, false); ++j; }                  // half nh-3: nothing left to issue
+    { DUN_WIDE_STEP(j, true, false, false); ++j; }                 // half nh-2: the last DMA must land
+    DUN_WIDE_STEP(j, false, false, false);                         // half nh-1
 #undef DUN_WIDE_STEP
 
     // rank-1 term of the head (C += u v^T, one output; host: never together with bias / ReLU): one more k step with
@@ -1140,9 +1144,9 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     {
         // 128 x 256 tiles where they fill the chip without split-K (the trunk's forward and dX GEMMs): the per-tile
         // prologue / store bubble is paid once per twice the work.  DUN_GEMM_WIDE=0 keeps 128 x 128 tiles.
-        static const int env_wide = getenv("DUN_GEMM_WIDE") ? atoi(getenv("DUN_GEMM_WIDE")) : 0;  // (off until measured)
+        static const int env_wide = getenv("DUN_GEMM_WIDE") ? atoi(getenv("DUN_GEMM_WIDE")) : 1;
         if (env_wide && dma && fits32 && !g_dma_two_buffer && p.ksplit == 1 && d->N % WBN == 0 &&
-            (long long)p.gridM * (d->N / WBN) >= 512 && (!d->R || p.rinit) &&
+            (long long)p.gridM * (d->N / WBN) >= 512 && d->K >= 64 && (!d->R || p.rinit) &&
             (!d->U || (d->O == 1 && !d->bias && !d->relu)) &&
             (d->a_kcontig || !d->b_kcontig)) {  // (the <M-contiguous, K-contiguous> instantiation spills: none of the trunk's GEMMs)
             p.wide = 1;

@@ -84,8 +84,9 @@ def med(d):
 
 # bench.py's roofline names -> substring of the kernel symbol that runs it in the training step
 ROLE = {
-    "gemm_fwd": "gemm_f32_dma4_kernel<true, true>",
-    "gemm_dx": "gemm_f32_dma4_kernel<true, false>",   # (only with DUN_DX_TRANSPOSED=0: dX runs on <true, true> otherwise)
+    # (the wide configuration's forward and dX GEMMs run on the 128x256-tile kernel; DUN_GEMM_WIDE=0: on dma4)
+    "gemm_fwd": ("gemm_f32_wide_kernel<true, true>", "gemm_f32_dma4_kernel<true, true>"),
+    "gemm_dx": ("gemm_f32_wide_kernel<true, false>", "gemm_f32_dma4_kernel<true, false>"),  # (only with DUN_DX_TRANSPOSED=0)
     "gemm_dw": "gemm_f32_dma4_kernel<false, false>",
     "head_fwd": "head_fwd_kernel",
     "head_bwd": "head_bwd_kernel",
@@ -122,7 +123,7 @@ def main():
         lines.append("gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of the bytes of 16-B/lane "
                      "streaming loads -> x2 column.  traffic = 2*FETCH + WRITE.")
         lines.append("")
-        # A kernel symbol that runs two different jobs in the step (gemm_f32_dma4_kernel<true, true>: the forward GEMM and,
+        # A kernel symbol that runs two different jobs in the step (gemm_f32_wide_kernel<true, true>: the forward GEMM and,
         # against the transposed weights, the dX GEMM with its residual / Z reads) has two clusters of FETCH_SIZE: split
         # its dispatches at the midpoint (the write pass is joined on the dispatch id: same program, same launch order)
         for k in list(fe):
@@ -151,10 +152,12 @@ def main():
             if os.path.exists(a.json):
                 cur = json.load(open(a.json))
             entry = {}
-            for role, sub in ROLE.items():
-                hits = [v for k, v in table.items() if sub in k and "[" not in k]
-                if hits:
-                    entry[role] = hits[0]
+            for role, subs in ROLE.items():
+                for sub in ((subs,) if isinstance(subs, str) else subs):
+                    hits = [v for k, v in table.items() if sub in k and "[" not in k]
+                    if hits:
+                        entry[role] = hits[0]
+                        break
             for role, tag in (("gemm_fwd", "[less read: forward]"), ("gemm_dx", "[more read: dX]")):
                 hits = [v for k, v in table.items() if tag in k]
                 if hits:
