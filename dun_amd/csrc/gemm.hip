@@ -2,7 +2,9 @@
 //
 // C[M,N] = epi(sum_k A(m,k) B(k,n)) on v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), so the
 // trunk keeps the reference's fp32 numerics (north-star: 1e-5 relative) while running on the matrix cores.
-// Three kernels share one epilogue:
+// Four kernels share one epilogue:
+//   gemm_f32_wide_kernel  whole 128x256 tiles, >= 512 of them, no split-K (the wide config's forward and dX GEMMs): the
+//                         LDS-DMA pipeline below on three stages with 2x4 accumulators per wave;
 //   gemm_f32_dma4_kernel  whole 128x128 tiles, 16-byte aligned operands, >= 128 tiles (every trunk GEMM of the wide
 //                         config): LDS-DMA staging through four 16-deep stages, mid-tile barrier, counted waits,
 //                         optional split-K (see the comment above the kernel);
