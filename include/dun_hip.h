@@ -167,7 +167,8 @@ typedef struct dun_gemm_desc {
      * registers (the trunk's dX GEMM writes the running gradient g; the BatchNorm backward of the block below starts
      * with sum_b g and sum_b g*xhat): bnz = that block's ReLU output Z [M, ldz], bn_mean / bn_rstd [N] its batch
      * statistics; bnstats float [2][T][N], T = dun_gemm_colstat_tiles(M, N): per row-tile column sums of C and of
-     * C * (Z - mean) * rstd. */
+     * C * (Z - mean) * rstd.  Not together with bias / ReLU / colstats, nor with a rank-O update of more than one
+     * column (DUN_ERR_UNSUPPORTED); a residual R is taken as the accumulators' starting value. */
     const float* bnz;
     const float* bn_mean;
     const float* bn_rstd;
