@@ -1099,7 +1099,11 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     const bool vb = aligned16(d->B) && d->ldb % 4 == 0 && (d->b_kcontig ? d->K % 4 == 0 : d->N % 4 == 0);
     const bool vec = va && vb;
     // whole tiles only: LDS-DMA cannot zero-fill, ragged problems take the register-staged kernel
-    const bool dma = !small && vec && d->M % BM == 0 && d->N % BN == 0 && d->K % BK == 0 && !g_force_generic;
+    // ... and the whole-tile kernels address C / R / Z tiles through buffer instructions with 32-bit byte offsets from the
+    // matrix base: a matrix of 2 GiB or more (batch >= 262144 at width 2048) takes the register-staged kernel's flat path
+    const auto below_2g = [&](int ld) { return ((long long)(d->M - 1) * ld + d->N) * 4 < (1ll << 31); };
+    const bool out32 = below_2g(d->ldc) && (!d->R || below_2g(d->ldr)) && (!d->bnz || below_2g(d->ldz));
+    const bool dma = !small && vec && out32 && d->M % BM == 0 && d->N % BN == 0 && d->K % BK == 0 && !g_force_generic;
     // One workgroup per CU cannot hide its own barriers: an epilogue-free problem with fewer tiles than 2 x 256 CUs and
     // a long K (dW = dU^T H: 256 tiles, K = batch) runs two K ranges per tile and adds them in a fixed order.
     p.ksplit = 1;

@@ -202,3 +202,28 @@ def test_full_batch_training_trajectory_against_the_oracle_on_device():
     assert rel(net.model.running_var, onet.p["running_var"]) < 1e-5
     assert rel(net.prob_model.q_logits.detach(), onet.q_logits) < 1e-4
     assert rel(net.f_neg_loglike.log_std.detach(), onet.log_std) < 1e-4
+
+
+def test_gemm_with_an_output_of_two_gibibytes():
+    """The whole-tile GEMM kernels address their output tiles with 32-bit byte offsets from the matrix base; an output of
+    2 GiB (batch 262144 at width 2048: fits a 288 GB GPU many times over) must take the flat-addressed kernel instead of
+    wrapping around.  Checked on the first and the last rows, where a wrapped offset would land."""
+    from dun_amd import kernels
+    be = kernels.backend()
+    M, N, K = 262144, 2048, 32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    Bw = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    Z, st = be.gemm(A, Bw, M, N, K, bias=bias, relu=True, colstats=True, out=out)
+    assert Z.data_ptr() == out.data_ptr()
+    for rows in (slice(0, 256), slice(M // 2 - 128, M // 2 + 128), slice(M - 256, M)):
+        ref = torch.relu(A[rows].double() @ Bw.double().t() + bias.double())
+        assert torch.isfinite(Z[rows]).all()
+        assert (Z[rows].double() - ref).abs().max().item() < 1e-4
+    assert bool(torch.isfinite(Z).all())
+    s1 = st[0].sum(0)
+    assert torch.allclose(s1, Z.double().sum(0), rtol=1e-9, atol=1e-6)
+    del Z, out, st
+    torch.cuda.empty_cache()
