@@ -1,6 +1,9 @@
 """Data feeding for the FC configs: the toy 'wiggle' regression set regenerated from its closed
 form (reference: src/datasets/additional_gap_loader.py:226-250), the UCI "gap"/standard split reader over a directory
-in the reference's on-disk layout (src/datasets/UCI_gap_loader.py:12-60; no download: there is no network), and a
+in the reference's on-disk layout (src/datasets/UCI_gap_loader.py:12-60; no download: there is no network), readers
+for the three toy sets the reference keeps as .npy files (agw_1d, matern_1d, my_1d: additional_gap_loader.py:65-223;
+parity unpinned: the reference has no fixture for them and its data files are not copied here -- tested on synthetic
+files of the same layout), and a
 device-resident batch iterator that keeps the epoch loop free of DataLoader workers and host-to-device copies.
 Loaders that download or read image corpora are out of scope."""
 import os
@@ -19,6 +22,42 @@ def load_wiggle():
     X = ((x - x.mean(axis=0)) / x.std(axis=0)).astype(np.float32)
     Y = ((y - y.mean(axis=0)) / y.std(axis=0)).astype(np.float32)
     return X, Y
+
+
+def _toy_file(base_dir, rel):
+    path = os.path.join(base_dir, rel)
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s not found (the reference downloads or regenerates it; point base_dir at a DUN "
+                                "checkout's experiments/data)" % path)
+    return np.load(path, allow_pickle=False)
+
+
+def load_agw_1d(base_dir, get_feats=False):
+    """The 1-d regression set of Izmailov et al. as the reference reads it (src/datasets/additional_gap_loader.py:65-90,
+    file <base_dir>/agw_data/data.npy, columns x, y): standardised inputs [n,1] (or, get_feats, the standardised
+    quadratic features [x/2, (x/2)^2], [n,2]) and standardised targets [n,1], float32.  No download."""
+    d = _toy_file(base_dir, os.path.join("agw_data", "data.npy"))
+    x, y = d[:, 0], d[:, 1][:, None]
+    f = np.hstack([x[:, None] / 2.0, (x[:, None] / 2.0) ** 2])
+    X = ((x - x.mean(axis=0)) / x.std(axis=0)).astype(np.float32)
+    Y = ((y - y.mean(axis=0)) / y.std(axis=0)).astype(np.float32)
+    F = ((f - f.mean(axis=0)) / f.std(axis=0)).astype(np.float32)
+    return (F, Y) if get_feats else (X[:, None], Y)
+
+
+def load_matern_1d(base_dir):
+    """Stored draw of the two-cluster Matern GP set (additional_gap_loader.py:113-158, file
+    <base_dir>/matern_data/matern_1d.npy, columns x, y): x [n,1], y [n,1] as stored.  The reference regenerates the draw
+    with GPy when the file is missing; here a missing file raises."""
+    xy = _toy_file(base_dir, os.path.join("matern_data", "matern_1d.npy"))
+    return xy[:, 0][:, None], xy[:, 1][:, None]
+
+
+def load_my_1d(base_dir):
+    """Stored draw of the reference's own 1-d set (additional_gap_loader.py:161-223, file
+    <base_dir>/my_1d_data/my_1d_data.npy, columns X_train, y_train (homoscedastic), X_test, y_test): each [n,1] float32."""
+    xy = _toy_file(base_dir, os.path.join("my_1d_data", "my_1d_data.npy"))
+    return tuple(xy[:, i, None].astype(np.float32) for i in range(4))
 
 
 class Datafeed(data.Dataset):

@@ -376,3 +376,37 @@ def test_one_row_training_batch_raises_like_batchnorm(cpu_backend):
     full = net.predict(x[:4])
     assert torch.allclose(net.predict(x[2:3]), full[2:3], rtol=1e-5, atol=1e-6)
     assert len(net.eval(x[:1], y[:1])) == 2
+
+
+def test_file_based_toy_loaders(tmp_path):
+    """load_agw_1d / load_matern_1d / load_my_1d read the .npy layouts of the reference's experiments/data directory
+    (src/datasets/additional_gap_loader.py:65-223).  Parity unpinned by reference data: synthetic files of the same
+    layout, the standardisation restated here; a missing file raises instead of downloading."""
+    from dun_amd.datasets import load_agw_1d, load_matern_1d, load_my_1d
+    rs = np.random.RandomState(7)
+    base = str(tmp_path)
+    for sub in ("agw_data", "matern_data", "my_1d_data"):
+        os.makedirs(os.path.join(base, sub))
+    agw = np.stack([rs.uniform(-8, 8, 400), rs.randn(400) * 3 + 1], axis=1)
+    np.save(os.path.join(base, "agw_data", "data.npy"), agw)
+    mat = rs.randn(200, 2)
+    np.save(os.path.join(base, "matern_data", "matern_1d.npy"), mat)
+    my = rs.randn(250, 4)
+    np.save(os.path.join(base, "my_1d_data", "my_1d_data.npy"), my)
+
+    X, Y = load_agw_1d(base)
+    assert X.shape == (400, 1) and Y.shape == (400, 1) and X.dtype == Y.dtype == np.float32
+    assert np.allclose(X[:, 0], (agw[:, 0] - agw[:, 0].mean()) / agw[:, 0].std(), atol=1e-6)
+    assert np.allclose(Y[:, 0], (agw[:, 1] - agw[:, 1].mean()) / agw[:, 1].std(), atol=1e-6)
+    assert abs(float(X.mean())) < 1e-5 and abs(float(X.std()) - 1) < 1e-5
+    F, Y2 = load_agw_1d(base, get_feats=True)
+    f = np.stack([agw[:, 0] / 2, (agw[:, 0] / 2) ** 2], axis=1)
+    assert F.shape == (400, 2) and np.allclose(F, (f - f.mean(0)) / f.std(0), atol=1e-5) and np.array_equal(Y, Y2)
+    x, y = load_matern_1d(base)
+    assert x.shape == y.shape == (200, 1) and np.array_equal(x[:, 0], mat[:, 0]) and np.array_equal(y[:, 0], mat[:, 1])
+    parts = load_my_1d(base)
+    assert len(parts) == 4
+    for i, t in enumerate(parts):
+        assert t.shape == (250, 1) and t.dtype == np.float32 and np.array_equal(t[:, 0], my[:, i].astype(np.float32))
+    with pytest.raises(FileNotFoundError):
+        load_agw_1d(os.path.join(base, "nowhere"))
