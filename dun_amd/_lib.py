@@ -22,7 +22,11 @@ EXPORTS = [
     "dun_fc_workspace_floats", "dun_fc_obj_num_partials", "dun_fc_head_is_fused", "dun_fc_forward", "dun_fc_backward", "dun_fc_input_layer", "dun_fc_block_linear",
     "dun_fc_block_norm", "dun_fc_block_apply", "dun_fc_head", "dun_fc_head_depth", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply", "dun_fc_bwd_block_dx", "dun_fc_bwd_block_dw",
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
+    "dun_sgd_step_multi", "dun_predict_gauss_step", "dun_fc_small_net_mode", "dun_fc_sync_bytes", "dun_fc_sync_status",
+    "dun_fc_objective_in_forward", "dun_fc_head_grads_in_forward",
 ]
+
+SGD_MAX_SEGMENTS = 24
 
 
 def res_floats(D):
@@ -59,7 +63,16 @@ class FcCtx(C.Structure):
                 ("obj_y", C.c_void_p), ("obj_w", C.c_void_p), ("obj_w_is_logits", C.c_int),
                 ("obj_log_std", C.c_void_p), ("obj_inv_batch", C.c_float), ("obj_dact", C.c_void_p),
                 ("obj_partials", C.c_void_p), ("obj_dwpart", C.c_void_p), ("obj_dbpart", C.c_void_p),
-                ("head_grads_from_forward", C.c_int)]
+                ("head_grads_from_forward", C.c_int),
+                ("num_batches_tracked", C.c_void_p), ("sync", C.c_void_p), ("sync_bytes", C.c_size_t),
+                ("obj_fin_result", C.c_void_p), ("obj_fin_sums", C.c_void_p), ("obj_fin_q_logits", C.c_void_p),
+                ("obj_fin_logprior", C.c_void_p), ("obj_fin_prior_ll", C.c_void_p),
+                ("obj_fin_N_train", C.c_double), ("obj_fin_batch", C.c_double), ("obj_fin_beta", C.c_double),
+                ("obj_fin_eps", C.c_double), ("obj_fin_objective", C.c_int)]
+
+
+class SgdSegment(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("buf", C.c_void_p), ("n", C.c_size_t)]
 
 
 _lib = None
@@ -107,6 +120,13 @@ def _declare(lib):
         "dun_head_backward_workspace_floats": (sz, [i, i, i]),
         "dun_head_backward": (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]),
         "dun_sgd_step": (i, [vp, vp, vp, sz, f, f, f, vp]),
+        "dun_sgd_step_multi": (i, [C.POINTER(SgdSegment), i, f, f, f, vp]),
+        "dun_predict_gauss_step": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "dun_fc_small_net_mode": (i, [i]),
+        "dun_fc_sync_bytes": (sz, [i, i]),
+        "dun_fc_sync_status": (i, [C.POINTER(FcCtx), vp]),
+        "dun_fc_objective_in_forward": (i, [C.POINTER(FcCtx)]),
+        "dun_fc_head_grads_in_forward": (i, [C.POINTER(FcCtx)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

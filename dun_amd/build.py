@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdun_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "elbo.hip", "head.hip", "trunk.hip", "smallnet.hip"]
+SOURCES = ["api.hip", "gemm.hip", "elbo.hip", "head.hip", "trunk.hip", "smallnet.hip", "persist.hip"]
 ARCH = "gfx950"
 
 
@@ -33,7 +33,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False):
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "dun_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "depth_finalize.h"), os.path.join(HERE, "..", "include", "dun_hip.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

@@ -14,5 +14,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace dun
 
-extern "C" int dun_abi_version(void) { return 3; }
+extern "C" int dun_abi_version(void) { return 4; }
 extern "C" const char* dun_last_error(void) { return dun::g_err; }

@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "depth_finalize.h"
 
 namespace dun {
 
@@ -439,114 +440,7 @@ __global__ __launch_bounds__(64) void reduce_rows_f64_kernel(const double* __res
     if (lane == 0) out[j] = s;
 }
 
-// One wavefront turns the per-depth sums into everything the objective and its backward need (fp64 inside).
-// `sums` may live in global memory or in LDS (generic pointer).
-__device__ __forceinline__ void depth_finalize_body(const double* sums, int gaussian,
-                                                    const float* __restrict__ q_logits,
-                                                    const float* __restrict__ logprior,
-                                                    const float* __restrict__ prior_ll,
-                                                    const float* __restrict__ log_std, int D, double N, double batch,
-                                                    double beta, double eps, int objective, float* __restrict__ res) {
-    const int lane = threadIdx.x & 63;
-    float* joint_o = res + DUN_RES_HEADER;
-    float* w_o = joint_o + D;
-    float* dq_o = w_o + D;
-    float* post_o = dq_o + D;
-    float* llsum_o = post_o + D;
-
-    double sigma = 1.0, live = 0.0;
-    if (gaussian) {
-        const double raw = exp((double)log_std[0]);
-        // the reference clamps in fp32: compare in fp32 so the branch agrees with it at the boundary
-        live = (expf(log_std[0]) >= 1e-4f) ? 1.0 : 0.0;
-        sigma = live != 0.0 ? raw : (double)1e-4f;
-    }
-    const double inv_var = 1.0 / (sigma * sigma);
-
-    // joint and the exact marginal / posterior
-    double mx = -INFINITY;
-    for (int d = lane; d < D; d += 64) {
-        const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
-        const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
-        llsum_o[d] = (float)LL;
-        joint_o[d] = (float)J;
-        mx = fmax(mx, J + (double)logprior[d]);
-    }
-    mx = wave_max(mx);
-    double se = 0.0;
-    for (int d = lane; d < D; d += 64) {
-        const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
-        const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
-        se += exp(J + (double)logprior[d] - mx);
-    }
-    se = wave_sum(se);
-    const double log_marg = mx + log(se);
-
-    // q = softmax(q_logits) and log q = log_softmax(q_logits) in fp32, exactly the arithmetic the reference's
-    // F.softmax / F.log_softmax do: a q_d that underflows to 0 there is 0 here (and gets the eps clamp).
-    float qmx = -INFINITY, qs = 0.f;
-    if (objective == DUN_OBJ_VI) {
-        for (int d = lane; d < D; d += 64) qmx = fmaxf(qmx, q_logits[d]);
-        qmx = wave_max(qmx);
-        for (int d = lane; d < D; d += 64) qs += expf(q_logits[d] - qmx);
-        qs = wave_sum(qs);
-    }
-    const float log_qs = logf(qs);
-
-    double E = 0.0, KL = 0.0, Asum = 0.0, Csum = 0.0, dls = 0.0;
-    for (int d = lane; d < D; d += 64) {
-        const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
-        const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
-        const double lp = (double)logprior[d];
-        const double post = exp(J + lp - log_marg);
-        post_o[d] = (float)post;
-        double wgt = post;
-        if (objective == DUN_OBJ_VI) {
-            const double lq = (double)((q_logits[d] - qmx) - log_qs);
-            const double q = (double)(expf(q_logits[d] - qmx) / qs);
-            const double c = fmin(fmax(q, eps), 1.0 - eps);
-            const double m = (q >= eps && q <= 1.0 - eps) ? 1.0 : 0.0;
-            E += q * J;
-            KL += c * (lq - lp);
-            Asum += m * q * (lq - lp);
-            Csum += c;
-            wgt = q;
-        }
-        w_o[d] = (float)wgt;
-        if (gaussian) dls += wgt * (sums[d] * inv_var - batch);
-    }
-    E = wave_sum(E);
-    KL = wave_sum(KL);
-    Asum = wave_sum(Asum);
-    Csum = wave_sum(Csum);
-    dls = wave_sum(dls);
-
-    for (int d = lane; d < D; d += 64) {
-        double dq = 0.0;
-        if (objective == DUN_OBJ_VI) {
-            const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
-            const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
-            const double lp = (double)logprior[d];
-            const double lq = (double)((q_logits[d] - qmx) - log_qs);
-            const double q = (double)(expf(q_logits[d] - qmx) / qs);
-            const double c = fmin(fmax(q, eps), 1.0 - eps);
-            const double m = (q >= eps && q <= 1.0 - eps) ? 1.0 : 0.0;
-            const double dKL = m * q * (lq - lp) - q * Asum + c - q * Csum;
-            dq = -(1.0 / N) * (q * (J - E) - beta * dKL);
-        }
-        dq_o[d] = (float)dq;
-    }
-    if (lane == 0) {
-        res[DUN_RES_OBJECTIVE] = (float)(objective == DUN_OBJ_VI ? E - beta * KL : log_marg);
-        res[DUN_RES_E_LOGLIKE] = (float)E;
-        res[DUN_RES_KL] = (float)KL;
-        res[DUN_RES_LOG_MARG] = (float)log_marg;
-        res[DUN_RES_DLOG_STD] = (float)(gaussian ? -(1.0 / batch) * dls * live : 0.0);
-        res[5] = 0.f;
-        res[6] = 0.f;
-        res[7] = 0.f;
-    }
-}
+// depth_finalize_body: depth_finalize.h
 
 __global__ __launch_bounds__(64) void depth_finalize_kernel(const double* __restrict__ sums, int gaussian,
                                                             const float* __restrict__ q_logits,
@@ -596,15 +490,34 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
                                                             int D, int n, float* __restrict__ mean,
                                                             float* __restrict__ std, const float* __restrict__ y,
                                                             const float* __restrict__ log_std,
-                                                            double* __restrict__ partials, int nparts) {
+                                                            double* __restrict__ partials, int nparts,
+                                                            int q_is_logits, float* __restrict__ q_out,
+                                                            const float* __restrict__ obj_src,
+                                                            double* __restrict__ obj_dst) {
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int idx = (blockIdx.x * 256 + tid) * 4;
     float mu[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
     const bool any = idx < n;
+    // q given as logits (the post-step q(d) of DUN_VI.fit): softmax in fp32 as F.softmax, every wavefront for itself
+    float qmx = 0.f, qinv = 1.f;
+    if (q_is_logits) {
+        const int lane = tid & 63;
+        qmx = -INFINITY;
+        for (int i = lane; i < D; i += 64) qmx = fmaxf(qmx, q[i]);
+        qmx = wave_allmax(qmx);
+        float s = 0.f;
+        for (int i = lane; i < D; i += 64) s += expf(q[i] - qmx);
+        qinv = wave_allsum(s);
+    }
+    if (blockIdx.x == 0) {
+        if (q_out)
+            for (int i = tid; i < D; i += 256) q_out[i] = q_is_logits ? expf(q[i] - qmx) / qinv : q[i];
+        if (obj_dst && tid == 0) obj_dst[0] = (double)obj_src[0];
+    }
     if (any) {
         for (int d = 0; d < D; ++d) {
-            const float qd = q[d];
+            const float qd = q_is_logits ? expf(q[d] - qmx) / qinv : q[d];
             const float* a = act + (size_t)d * n + idx;
             float v[4];
             if (VEC) {
@@ -1181,12 +1094,13 @@ extern "C" int dun_elbo_gauss_static(const float* act, const float* y, const flo
                            stream, "dun_elbo_gauss_static");
 }
 
-extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std,
-                                 const float* y, const float* log_std, double* partials, double* metrics,
-                                 dun_stream_t stream) {
-    DUN_REQUIRE(act && q && mean, "dun_predict_gauss: null pointer");
-    DUN_REQUIRE(D > 0 && n > 0, "dun_predict_gauss: empty input");
-    DUN_REQUIRE(metrics == nullptr || (y && log_std && partials), "dun_predict_gauss: metrics need y, log_std, partials");
+static int predict_gauss_impl(const float* act, const float* q, int q_is_logits, int D, int n, float* mean, float* std,
+                              const float* y, const float* log_std, double* partials, double* metrics, float* q_out,
+                              const float* obj_src, double* obj_dst, dun_stream_t stream, const char* who) {
+    DUN_REQUIRE(act && q && mean, "%s: null pointer", who);
+    DUN_REQUIRE(D > 0 && n > 0, "%s: empty input", who);
+    DUN_REQUIRE(metrics == nullptr || (y && log_std && partials), "%s: metrics need y, log_std, partials", who);
+    DUN_REQUIRE((obj_src == nullptr) == (obj_dst == nullptr), "%s: objective_src and objective_dst go together", who);
     const int nparts = dun_predict_num_partials(n, 1);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // one workgroup: its [2][1] partials ARE the metric sums, no reduction launch
@@ -1194,19 +1108,34 @@ extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n,
     const bool vec = (n % 4 == 0) && aligned16(act);
     if (vec && stream_nt((size_t)D * n * 4))
         hipLaunchKernelGGL((predict_gauss_kernel<true, true>), dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst);
     else if (vec)
         hipLaunchKernelGGL(predict_gauss_kernel<true>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst);
     else
         hipLaunchKernelGGL(predict_gauss_kernel<false>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst);
     DUN_LAUNCH_CHECK();
     if (metrics && nparts > 1) {
         hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);
         DUN_LAUNCH_CHECK();
     }
     return DUN_OK;
+}
+
+extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std,
+                                 const float* y, const float* log_std, double* partials, double* metrics,
+                                 dun_stream_t stream) {
+    return predict_gauss_impl(act, q, 0, D, n, mean, std, y, log_std, partials, metrics, nullptr, nullptr, nullptr, stream,
+                              "dun_predict_gauss");
+}
+
+extern "C" int dun_predict_gauss_step(const float* act, const float* q, int q_is_logits, int D, int n, float* mean,
+                                      float* std, const float* y, const float* log_std, double* partials, double* metrics,
+                                      float* q_out, const float* objective_src, double* objective_dst,
+                                      dun_stream_t stream) {
+    return predict_gauss_impl(act, q, q_is_logits, D, n, mean, std, y, log_std, partials, metrics, q_out, objective_src,
+                              objective_dst, stream, "dun_predict_gauss_step");
 }
 
 extern "C" int dun_predict_softmax(const float* act, const float* q, int D, int B, int C, float* probs,

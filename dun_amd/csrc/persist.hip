@@ -1,0 +1,723 @@
+// One-launch forward and one-launch backward for SMALL residual-MLP DUNs (toy / UCI configurations: width <= 128,
+// batch <= 2048, one output) -- src/DUN/stochastic_fc_models.py:62-70 over src/DUN/layers.py:33-53 in the reference.
+//
+// smallnet.hip runs such a net as one launch per block (a workgroup owns four feature columns for every row); the step
+// is then ~30 dependent launches of 4-10 us, and each launch re-ingests the whole [B,W] hidden state per workgroup.
+// Here the ROWS are owned instead: workgroup p keeps rows [16p, 16p+16) of the batch through ALL blocks.
+//   * Linear layers are row-independent: the 16 x W hidden tile lives in LDS, the [16,W] x [W,W] product runs on
+//     v_mfma_f32_16x16x4_f32 (wave w owns output columns [16w, 16w+16); its slice of W_i sits in registers, fetched
+//     while the previous block's exchange is in flight), so no hidden state ever crosses workgroups.
+//   * BatchNorm1d couples rows through per-column batch statistics only: each wave leaves ONE 16-byte record per
+//     column {partial a, tag, partial b, tag} (forward: Welford mean / M2 of its 16 rows, cancellation-free in fp32;
+//     backward: sum g, sum g*xhat) with a write-through (sc1) store, and reads the P records of its own 16 columns with
+//     sc1 loads until every tag carries this phase's number -- the data is its own flag (MI355X guide, Guideline 16
+//     R2), so there is no grid barrier, no fence, no counter on the per-block path, and waves exchange independently
+//     of each other.  Totals are added in fp64 in a fixed order (bitwise reproducible).  Two record slots alternate by
+//     phase parity; tags count up across launches from an epoch word in the sync buffer, so nothing is zeroed per call
+//     (graph replays included: the epoch lives in device memory, not in a kernel argument).
+//   * The shared head (one output), the Gaussian likelihood terms (act, d loss / d act, per-depth sums of squared
+//     residuals), the head's weight / bias gradient partials and -- by the workgroup whose partial sums arrive last --
+//     the whole depth-level finalisation (dun_depth_finalize_partials' arithmetic) ride in the forward launch.
+// Every spin is bounded by the wall clock; a wave that gives up records a code in sync[1], the launch drains with
+// every later wait skipped, and the outputs of that call are NaN.
+#include <math.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "depth_finalize.h"
+
+namespace dun {
+
+constexpr int PN_T = 512;     // 8 waves: one 16-column MFMA tile each
+constexpr int PN_R = 16;      // rows of the batch a workgroup owns
+constexpr int PN_MAX_P = 128;
+constexpr int PN_MAX_W = 128;
+constexpr int PN_MAX_L = 255;
+constexpr int PN_HDR_BYTES = 256;    // sync header: word 0 epoch, word 1 error code, word 2 finalisation ticket
+constexpr int PN_REC_STRIDE = 128;   // records per (parity, workgroup) row, one per column
+constexpr long long PN_TIMEOUT_TICKS = 200000000LL;  // wall_clock64 runs at 100 MHz: 2 s
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+static int g_small_net_mode = -1;  // -1: take it from the environment on first use
+
+int small_net_mode() {
+    if (g_small_net_mode < 0) {
+        const char* off = getenv("DUN_SMALLNET");
+        const char* pers = getenv("DUN_SMALLNET_PERSIST");
+        g_small_net_mode = (off && off[0] == '0') ? 0 : ((pers && pers[0] == '0') ? 1 : 2);
+    }
+    return g_small_net_mode;
+}
+
+static inline int pn_workgroups(int B) { return (B + PN_R - 1) / PN_R; }
+size_t pn_sync_bytes(int B, int W) {
+    if (W < 4 || W > PN_MAX_W || (W & 3) || B < 1 || B > PN_R * PN_MAX_P) return 0;
+    return (size_t)PN_HDR_BYTES + (size_t)2 * pn_workgroups(B) * PN_REC_STRIDE * 16;
+}
+
+bool pn_eligible(const dun_fc_ctx* c) {
+    if (small_net_mode() != 2) return false;
+    const size_t need = pn_sync_bytes(c->B, c->W);
+    if (need == 0 || c->sync == nullptr || c->sync_bytes < need) return false;
+    if (c->O != 1 || c->L > PN_MAX_L) return false;
+    return aligned16(c->p.w) && (reinterpret_cast<uintptr_t>(c->sync) & 255) == 0;
+}
+
+// ---- exchange of per-column partials between the row-owning workgroups ---------------------------------------------------
+struct PnXch {
+    __amdgpu_buffer_rsrc_t rs;  // the sync buffer
+    unsigned* words;            // its header
+    int* abort_flag;            // LDS: a wave of this workgroup has given up
+    int P, pid;
+};
+
+__device__ __forceinline__ int pn_rec_offset(int parity, int P, int p, int col) {
+    return PN_HDR_BYTES + ((parity * P + p) * PN_REC_STRIDE + col) * 16;
+}
+
+__device__ __forceinline__ void pn_publish(const PnXch& x, int parity, int col, float a, float b, unsigned tag) {
+    const u32x4 v = {__float_as_uint(a), tag, __float_as_uint(b), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(v, x.rs, pn_rec_offset(parity, x.P, x.pid, col), 0, 16);  // aux 16 = sc1
+}
+
+// Lane (j = lane & 15, q = lane >> 4) reads the records of column `col` from workgroups q, q+4, q+8, ... and adds them
+// in that order; the four lane groups are then combined ((q0 + q1) + (q2 + q3)), so every lane of a column ends with the
+// same fp64 totals.  WELFORD: the records are {mean, M2} of n_p rows -> t1 = sum n_p mean_p, t2 = sum M2_p + n_p mean_p^2.
+template <bool WELFORD>
+__device__ __forceinline__ void pn_gather(const PnXch& x, int parity, int col, bool active, unsigned tag, int B,
+                                          unsigned code, double& t1, double& t2) {
+    constexpr int CH = 8;
+    const int lane = threadIdx.x & 63, q = lane >> 4;
+    const int M = (x.P + 3) >> 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int m0 = 0; m0 < M; m0 += CH) {
+        u32x4 g[CH];
+        const long long t_begin = wall_clock64();
+        for (;;) {
+            // (compiler barrier: the records change under this loop; it keeps the loads inside it and, with every
+            // access to them being an sc1 buffer access, nothing of them is cached in registers or L1)
+            asm volatile("" ::: "memory");
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int pi = q + 4 * (m0 + u);
+                g[u] = __builtin_amdgcn_raw_buffer_load_b128(x.rs, pn_rec_offset(parity, x.P, min(pi, x.P - 1), col), 0, 16);
+                ok = ok && (!(active && pi < x.P) || (g[u][1] == tag && g[u][3] == tag));
+            }
+            if (__all(ok)) break;
+            if (*reinterpret_cast<volatile int*>(x.abort_flag)) break;  // this launch is already lost: drain
+            if (wall_clock64() - t_begin > PN_TIMEOUT_TICKS) {
+                if (lane == 0) {
+                    *reinterpret_cast<volatile int*>(x.abort_flag) = 1;
+                    __hip_atomic_store(x.words + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int pi = q + 4 * (m0 + u);
+            if (active && pi < x.P) {
+                // (through scalars: __builtin_bit_cast applied to a vector ELEMENT read element 0 for both, ROCm 7.2)
+                const unsigned ua = g[u][0], ub = g[u][2];
+                const double a = (double)__uint_as_float(ua);
+                const double b = (double)__uint_as_float(ub);
+                if (WELFORD) {
+                    const double n = (double)min(PN_R, B - PN_R * pi);
+                    s1 += n * a;
+                    s2 += b + n * a * a;
+                } else {
+                    s1 += a;
+                    s2 += b;
+                }
+            }
+        }
+    }
+    const int j = lane & 15;
+    t1 = (__shfl(s1, j, 64) + __shfl(s1, j + 16, 64)) + (__shfl(s1, j + 32, 64) + __shfl(s1, j + 48, 64));
+    t2 = (__shfl(s2, j, 64) + __shfl(s2, j + 16, 64)) + (__shfl(s2, j + 32, 64) + __shfl(s2, j + 48, 64));
+}
+
+// sum over the four lane groups of a wave (rows 4q .. 4q+3 of a column live in lane group q of the MFMA result layout)
+__device__ __forceinline__ float pn_sum_groups(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ float pn_row16_sum(float v) {
+    v += dpp_move<DPP_QUAD_XOR1>(v);
+    v += dpp_move<DPP_QUAD_XOR2>(v);
+    v += dpp_move<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_move<DPP_ROW_MIRROR>(v);
+    return v;
+}
+
+// [16, K] x [K, 16] on v_mfma_f32_16x16x4_f32: A rows from the LDS tile (16-byte reads along k), this wave's operand
+// columns in registers.  MFMA step (s, e) contracts k = 16 s + 4 (lane >> 4) + e on both operands; two accumulators
+// alternate over s so that consecutive MFMAs do not wait for each other's result.
+template <int NT>
+__device__ __forceinline__ f32x4 pn_tile_matmul(const float* tile, int ld, const f32x4 (&wq)[NT]) {
+    const int lane = threadIdx.x & 63;
+    const float* arow = tile + (lane & 15) * ld + 4 * (lane >> 4);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        const f32x4 aq = *reinterpret_cast<const f32x4*>(arow + 16 * s);
+        if (s & 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[e], wq[s][e], acc1, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[e], wq[s][e], acc0, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+
+struct PnFwdP {
+    int B, din, W, depth, residual, P;
+    const float* x;
+    const float *w_in, *b_in, *w_out, *b_out, *w, *b, *gamma, *beta;
+    float *running_mean, *running_var;
+    float *H, *Z, *bn_mean, *bn_rstd, *act;
+    long long* nbt;
+    float eps, momentum;
+    unsigned* sync;
+    int sync_bytes;
+    // likelihood pass (y == NULL: plain forward)
+    const float* y;
+    const float* qw;  // depth weights / logits, or NULL (sums only)
+    int w_is_logits;
+    const float* log_std;
+    float inv_batch;
+    float* dact;
+    double* partials;  // [depth+1][nparts]
+    int nparts;
+    float* dwpart;     // [P][W] or NULL
+    float* dbpart;     // [P]
+    // finalisation by the last workgroup (fin_result == NULL: none)
+    float* fin_result;
+    double* fin_sums;
+    const float *fin_q_logits, *fin_logprior, *fin_prior_ll;
+    double fin_N, fin_batch, fin_beta, fin_eps;
+    int fin_objective;
+};
+
+template <int NT, bool TRAIN>
+__global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
+    constexpr int WP = 16 * NT, LD = WP + 4;
+    __shared__ __attribute__((aligned(16))) float hT[2][PN_R][LD];
+    __shared__ __attribute__((aligned(16))) float s_gw[PN_R][WP];
+    __shared__ float s_rsq[PN_MAX_L + 1][PN_R];
+    __shared__ float s_coef[PN_MAX_L + 1];
+    __shared__ float s_gb[PN_R];
+    __shared__ double s_sums[PN_MAX_L + 1];
+    __shared__ int s_abort, s_ticket;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pid = blockIdx.x, r0 = pid * PN_R;
+    const int B = p.B, W = p.W, depth = p.depth, D = depth + 1;
+    const int nvalid = min(PN_R, B - r0);
+    const bool exchanging = TRAIN && depth > 0;
+
+    PnXch xch;
+    xch.rs = __builtin_amdgcn_make_buffer_rsrc(p.sync, 0, p.sync_bytes, 0x00020000);
+    xch.words = p.sync;
+    xch.abort_flag = &s_abort;
+    xch.P = p.P;
+    xch.pid = pid;
+    unsigned base = 0;
+    if (exchanging) base = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) s_abort = 0;
+
+    // per-depth coefficient of the likelihood gradient: d(-objective/N)/d act = coef_d * (y - act)
+    const bool has_obj = p.y != nullptr;
+    if (has_obj && wv == 0) {
+        const float sigma = fmaxf(expf(p.log_std[0]), 1e-4f);
+        const float scale = -p.inv_batch / (sigma * sigma);
+        float mx = 0.f, ssum = 1.f;
+        if (p.qw && p.w_is_logits) {
+            mx = -INFINITY;
+            for (int d = lane; d < D; d += 64) mx = fmaxf(mx, p.qw[d]);
+            mx = wave_allmax(mx);
+            ssum = 0.f;
+            for (int d = lane; d < D; d += 64) ssum += expf(p.qw[d] - mx);
+            ssum = wave_allsum(ssum);
+        }
+        for (int d = lane; d < D; d += 64) {
+            float wd = 0.f;
+            if (p.qw) wd = p.w_is_logits ? expf(p.qw[d] - mx) / ssum : p.qw[d];
+            s_coef[d] = wd * scale;
+        }
+    }
+
+    // ---- input layer (no activation): thread (c, rq) takes rows 4rq .. 4rq+3 of column c ------------------------------
+    {
+        const int c = t & 127, rq = t >> 7;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < W) {
+            const float* wr = p.w_in + (size_t)c * p.din;
+            const float* xr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[j] = p.x + (size_t)min(r0 + 4 * rq + j, B - 1) * p.din;
+            for (int k = 0; k < p.din; ++k) {
+                const float wk = wr[k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = fmaf(xr[j][k], wk, a[j]);
+            }
+            const float bi = p.b_in[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += bi;
+        }
+        if (c < WP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 4 * rq + j;
+                const bool live = c < W && row < nvalid;
+                hT[0][row][c] = live ? a[j] : 0.f;
+                if (live) p.H[(size_t)(r0 + row) * W + c] = a[j];
+            }
+        }
+    }
+
+    // head: thread (row = t >> 5, part = t & 31) holds four columns of its row
+    const int hrow = t >> 5, hpart = t & 31;
+    f32x4 wo4 = {0.f, 0.f, 0.f, 0.f};
+    if (hpart * 4 < W) wo4 = *reinterpret_cast<const f32x4*>(p.w_out + hpart * 4);  // (W % 4 == 0; w_out 16-byte aligned: host)
+    const float b0 = p.b_out[0];
+    const float yv = has_obj ? p.y[min(r0 + hrow, B - 1)] : 0.f;
+    const bool want_dw = p.dwpart != nullptr;
+    f32x4 gw = {0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f;
+
+    auto head = [&](int d, const float (*hb)[LD]) {
+        f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+        if (hpart * 4 < WP) hv = *reinterpret_cast<const f32x4*>(&hb[hrow][hpart * 4]);
+        float dot = (hv[0] * wo4[0] + hv[1] * wo4[1]) + (hv[2] * wo4[2] + hv[3] * wo4[3]);
+        dot = pn_row16_sum(dot);
+        dot += __shfl_xor(dot, 16, 64);
+        const float a = dot + b0;
+        const bool live = hrow < nvalid;
+        float g = 0.f, rr = 0.f;
+        if (has_obj) {
+            const float r = yv - a;
+            rr = live ? r * r : 0.f;
+            g = live ? s_coef[d] * r : 0.f;
+        }
+        if (hpart == 0) {
+            if (live) {
+                p.act[(size_t)d * B + r0 + hrow] = a;
+                if (p.dact) p.dact[(size_t)d * B + r0 + hrow] = g;
+            }
+            s_rsq[d][hrow] = rr;
+        }
+        if (want_dw) {
+            gw += g * hv;
+            if (hpart == 0) gb += g;
+        }
+    };
+
+    // this wave's slice of a block's weights: wq[s][e] = W_i[n][16 s + 4 (lane >> 4) + e], n = 16 wv + (lane & 15)
+    const int col = 16 * wv + (lane & 15), q = lane >> 4;
+    const bool colok = wv < NT && col < W;
+    auto load_w = [&](int i, f32x4 (&dst)[NT]) {
+        const float* wi = p.w + (size_t)i * W * W + (size_t)min(col, W - 1) * W;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int k = 16 * s + 4 * q;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wi + min(k, W - 4));
+            dst[s] = (colok && k < W) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 wq[NT], wnext[NT];
+    if (depth > 0 && wv < NT) load_w(0, wq);
+
+    __syncthreads();  // h_0 tile, s_coef, s_abort
+    head(0, hT[0]);
+
+    for (int i = 0; i < depth; ++i) {
+        const float (*hc)[LD] = hT[i & 1];
+        float(*hn)[LD] = hT[(i + 1) & 1];
+        if (wv < NT) {
+            const size_t pi = (size_t)i * W + min(col, W - 1);
+            const float bias = p.b[pi], gm = p.gamma[pi], bt = p.beta[pi];
+            float rmean = 0.f, rvar = 1.f;
+            if (!TRAIN || pid == 0) {
+                rmean = p.running_mean[pi];
+                rvar = p.running_var[pi];
+            }
+            const f32x4 acc = pn_tile_matmul<NT>(&hc[0][0], LD, wq);
+            if (i + 1 < depth) load_w(i + 1, wnext);  // in flight under the exchange
+            float z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = fmaxf(acc[j] + bias, 0.f);
+            float mu, rs;
+            if (TRAIN) {
+                // Welford partial of this workgroup's rows: mean, then M2 around it (two passes over four registers)
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s += (4 * q + j < nvalid) ? z[j] : 0.f;
+                const float mean_p = pn_sum_groups(s) / (float)nvalid;
+                float m2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dlt = z[j] - mean_p;
+                    m2 += (4 * q + j < nvalid) ? dlt * dlt : 0.f;
+                }
+                m2 = pn_sum_groups(m2);
+                const unsigned tag = base + 1u + (unsigned)i;
+                if (q == 0 && colok) pn_publish(xch, i & 1, col, mean_p, m2, tag);
+                if (colok) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * q + j < nvalid) p.Z[((size_t)i * B + r0 + 4 * q + j) * W + col] = z[j];
+                }
+                double t1, t2;
+                pn_gather<true>(xch, i & 1, min(col, W - 1), colok, tag, B, 0x100u + (unsigned)i, t1, t2);
+                const double n = (double)B;
+                const double mean = t1 / n;
+                double var = t2 / n - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                const double rstd = 1.0 / sqrt(var + (double)p.eps);
+                mu = (float)mean;
+                rs = (float)rstd;
+                if (pid == 0 && q == 0 && colok) {
+                    const double mom = (double)p.momentum;
+                    p.bn_mean[pi] = mu;
+                    p.bn_rstd[pi] = rs;
+                    p.running_mean[pi] = (float)((1.0 - mom) * (double)rmean + mom * mean);
+                    p.running_var[pi] = (float)((1.0 - mom) * (double)rvar + mom * (var * (n / (n - 1.0))));
+                }
+            } else {
+                mu = rmean;
+                rs = 1.f / sqrtf(rvar + p.eps);
+            }
+            const float sc = gm * rs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 4 * q + j;
+                float o = (z[j] - mu) * sc + bt;
+                if (p.residual) o = hc[row][col] + o;
+                hn[row][col] = colok ? o : 0.f;
+                if (colok && row < nvalid) p.H[((size_t)(i + 1) * B + r0 + row) * W + col] = o;
+            }
+#pragma unroll
+            for (int s = 0; s < NT; ++s) wq[s] = wnext[s];
+        }
+        __syncthreads();  // h_{i+1} tile complete; every wave is done with the A operand of block i
+        head(i + 1, hn);
+    }
+
+    // ---- what the workgroup leaves behind -------------------------------------------------------------------------------
+    if (want_dw) {
+        if (hpart * 4 < WP) *reinterpret_cast<f32x4*>(&s_gw[hrow][hpart * 4]) = gw;
+        if (hpart == 0) s_gb[hrow] = gb;
+    }
+    __syncthreads();  // s_rsq, s_gw, s_gb, s_abort
+    const bool lost = s_abort != 0;
+    if (want_dw) {
+        if (t < W) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < PN_R; ++r) a += s_gw[r][t];
+            p.dwpart[(size_t)pid * W + t] = a;
+        }
+        if (t == 0) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < PN_R; ++r) a += s_gb[r];
+            p.dbpart[pid] = a;
+        }
+    }
+    if (pid == 0) {
+        if (TRAIN && p.nbt != nullptr && t < depth) p.nbt[t] += 1;
+        // tags of the next launch start behind this one's (every workgroup has read `base` by now: it published into
+        // the last exchange this workgroup completed)
+        if (exchanging && t == 0) __hip_atomic_store(p.sync, base + (unsigned)depth + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lost) {  // an exchange gave up: nothing computed from it may look valid
+        const float nanv = __builtin_nanf("");
+        for (int idx = t; idx < D * PN_R; idx += PN_T) {
+            const int d = idx / PN_R, r = idx % PN_R;
+            if (r < nvalid) p.act[(size_t)d * B + r0 + r] = nanv;
+        }
+    }
+    if (has_obj && p.partials != nullptr) {
+        const bool fin = p.fin_result != nullptr;
+        unsigned long long* pw = reinterpret_cast<unsigned long long*>(p.partials);
+        for (int d = t; d < D; d += PN_T) {
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < PN_R; ++r) a += (double)s_rsq[d][r];
+            if (lost) a = (double)__builtin_nanf("");
+            // (write-through: the finalising workgroup reads them inside this launch)
+            __hip_atomic_store(pw + (size_t)d * p.nparts + pid, __builtin_bit_cast(unsigned long long, a), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (fin) {
+            // every storing wave drains its stores, then ONE lane takes a ticket; the workgroup whose ticket is the last
+            // reads all partials (sc1 loads) and finishes the objective
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                const unsigned tk = __hip_atomic_fetch_add(p.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk == (unsigned)p.P - 1u) __hip_atomic_store(p.sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_ticket = (int)tk;
+            }
+            __syncthreads();
+            if (s_ticket == p.P - 1) {
+                for (int d = wv; d < D; d += PN_T / 64) {
+                    double a = 0.0;
+                    for (int i = lane; i < p.nparts; i += 64)
+                        a += __builtin_bit_cast(double, __hip_atomic_load(pw + (size_t)d * p.nparts + i, __ATOMIC_RELAXED,
+                                                                          __HIP_MEMORY_SCOPE_AGENT));
+                    a = wave_sum(a);
+                    if (lane == 0) {
+                        s_sums[d] = a;
+                        if (p.fin_sums) p.fin_sums[d] = a;
+                    }
+                }
+                __syncthreads();
+                if (wv == 0)
+                    depth_finalize_body(s_sums, 1, p.fin_q_logits, p.fin_logprior, p.fin_prior_ll, p.log_std, D, p.fin_N,
+                                        p.fin_batch, p.fin_beta, p.fin_eps, p.fin_objective, p.fin_result);
+            }
+        }
+    }
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------
+struct PnBwdP {
+    int B, W, L, residual, P;
+    const float *w, *w_out, *gamma;
+    const float *Z, *bn_mean, *bn_rstd;
+    const float* dact;  // [L+1][B]
+    float* dU;          // [L][B][W]
+    float* G;           // [B][W]: d loss / d h_0 (the input layer's output), for the weight-gradient launch
+    float *dgamma, *dbeta;
+    unsigned* sync;
+    int sync_bytes;
+};
+
+template <int NT>
+__global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
+    constexpr int WP = 16 * NT, LD = WP + 4;
+    __shared__ __attribute__((aligned(16))) float duT[2][PN_R][LD];
+    __shared__ int s_abort;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int pid = blockIdx.x, r0 = pid * PN_R;
+    const int B = p.B, W = p.W, L = p.L;
+    const int nvalid = min(PN_R, B - r0);
+
+    PnXch xch;
+    xch.rs = __builtin_amdgcn_make_buffer_rsrc(p.sync, 0, p.sync_bytes, 0x00020000);
+    xch.words = p.sync;
+    xch.abort_flag = &s_abort;
+    xch.P = p.P;
+    xch.pid = pid;
+    unsigned base = 0;
+    if (L > 0) base = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) s_abort = 0;
+    __syncthreads();
+
+    const int col = 16 * wv + (lane & 15), q = lane >> 4;
+    const bool colok = wv < NT && col < W;
+    const int colc = min(col, W - 1);
+    const float wo = colok ? p.w_out[colc] : 0.f;
+
+    auto dact_rows = [&](int d, float (&da)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + 4 * q + j;
+            const float v = p.dact[(size_t)d * B + min(row, B - 1)];
+            da[j] = row < B ? v : 0.f;
+        }
+    };
+    // operand of g = dU W_i: the contraction runs over W_i's OUTPUT index, wq[s][e] = W_i[16 s + 4 q + e][col]
+    auto load_w = [&](int i, f32x4 (&dst)[NT]) {
+        const float* wi = p.w + (size_t)i * W * W + colc;
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * s + 4 * q + e;
+                const float v = wi[(size_t)min(k, W - 1) * W];
+                dst[s][e] = (colok && k < W) ? v : 0.f;
+            }
+    };
+    auto load_z = [&](int i, float (&z)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = p.Z[((size_t)i * B + min(r0 + 4 * q + j, B - 1)) * W + colc];
+    };
+
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wv < NT) {
+        float da[4];
+        dact_rows(L, da);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = da[j] * wo;
+    }
+    f32x4 wq[NT];
+    float z[4] = {0.f, 0.f, 0.f, 0.f}, zn[4];
+    if (L > 0 && wv < NT) {
+        load_z(L - 1, z);
+        load_w(L - 1, wq);
+    }
+
+    for (int i = L - 1; i >= 0; --i) {
+        const int phase = L - 1 - i;
+        float(*dt)[LD] = duT[phase & 1];
+        if (wv < NT) {
+            const size_t pi = (size_t)i * W + colc;
+            const float mu = p.bn_mean[pi], rs = p.bn_rstd[pi], gm = p.gamma[pi];
+            float xh[4], sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[j] = (z[j] - mu) * rs;
+                sg += g[j];            // (rows past the batch carry g = 0)
+                sgx += g[j] * xh[j];
+            }
+            sg = pn_sum_groups(sg);
+            sgx = pn_sum_groups(sgx);
+            const unsigned tag = base + 1u + (unsigned)phase;
+            if (q == 0 && colok) pn_publish(xch, phase & 1, col, sg, sgx, tag);
+            if (i > 0) load_z(i - 1, zn);  // the next block's operands travel under the exchange
+            double t1, t2;
+            pn_gather<false>(xch, phase & 1, colc, colok, tag, B, 0x200u + (unsigned)phase, t1, t2);
+            const double inv_n = 1.0 / (double)B;
+            const float mg = (float)(t1 * inv_n), mgx = (float)(t2 * inv_n);
+            if (pid == 0 && q == 0 && colok) {
+                p.dbeta[pi] = (float)t1;
+                p.dgamma[pi] = (float)t2;
+            }
+            const float k0 = gm * rs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 4 * q + j;
+                const bool live = colok && row < nvalid;
+                const float du = (live && z[j] > 0.f) ? k0 * (g[j] - mg - xh[j] * mgx) : 0.f;
+                dt[row][col] = du;
+                if (live) p.dU[((size_t)i * B + r0 + row) * W + col] = du;
+            }
+        }
+        __syncthreads();  // dU tile of this block complete (the other slot is still being read by no one: see below)
+        if (wv < NT) {
+            const f32x4 acc = pn_tile_matmul<NT>(&dt[0][0], LD, wq);
+            if (i > 0) load_w(i - 1, wq);
+            float da[4];
+            dact_rows(i, da);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = (p.residual ? g[j] : 0.f) + acc[j] + da[j] * wo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = zn[j];
+        }
+        // (two dU slots: a wave writes slot (phase+1)&1 only after the barrier of phase, behind which every wave has finished
+        // reading slot (phase-1)&1 = (phase+1)&1 in the matmul of phase-1)
+    }
+    if (colok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * q + j < nvalid) p.G[(size_t)(r0 + 4 * q + j) * W + col] = g[j];
+    }
+    if (pid == 0 && t == 0 && L > 0)
+        __hip_atomic_store(p.sync, base + (unsigned)L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_abort && colok) {  // an exchange gave up: poison what the weight-gradient launch reads
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * q + j < nvalid) p.G[(size_t)(r0 + 4 * q + j) * W + col] = __builtin_nanf("");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------
+static inline int pn_tiles(int W) { return W <= 32 ? 2 : (W <= 64 ? 4 : (W <= 112 ? 7 : 8)); }
+
+int pn_forward(const dun_fc_ctx* c, hipStream_t s) {
+    if (c->train && c->depth > 0)
+        DUN_REQUIRE(c->B > 1, "dun_fc_forward: BatchNorm in train mode needs more than 1 row (got %d)", c->B);
+    DUN_REQUIRE(aligned16(c->p.w_out), "dun_fc_forward: w_out must be 16-byte aligned");
+    PnFwdP p;
+    memset(&p, 0, sizeof(p));
+    p.B = c->B; p.din = c->din; p.W = c->W; p.depth = c->depth; p.residual = c->residual;
+    p.P = pn_workgroups(c->B);
+    p.x = c->x;
+    p.w_in = c->p.w_in; p.b_in = c->p.b_in; p.w_out = c->p.w_out; p.b_out = c->p.b_out;
+    p.w = c->p.w; p.b = c->p.b; p.gamma = c->p.gamma; p.beta = c->p.beta;
+    p.running_mean = c->running_mean; p.running_var = c->running_var;
+    p.H = c->H; p.Z = c->Z; p.bn_mean = c->bn_mean; p.bn_rstd = c->bn_rstd; p.act = c->act;
+    p.nbt = reinterpret_cast<long long*>(c->num_batches_tracked);
+    p.eps = c->bn_eps; p.momentum = c->bn_momentum;
+    p.sync = c->sync; p.sync_bytes = (int)pn_sync_bytes(c->B, c->W);
+    if (c->obj_y) {
+        p.y = c->obj_y; p.qw = c->obj_w; p.w_is_logits = c->obj_w_is_logits; p.log_std = c->obj_log_std;
+        p.inv_batch = c->obj_inv_batch;
+        p.dact = c->obj_w ? c->obj_dact : nullptr;
+        p.partials = c->obj_partials;
+        p.nparts = p.P;
+        if (p.dact && c->obj_dwpart && c->obj_dbpart && c->train) { p.dwpart = c->obj_dwpart; p.dbpart = c->obj_dbpart; }
+        if (c->obj_fin_result) {
+            DUN_REQUIRE(c->obj_fin_logprior != nullptr, "dun_fc_forward: obj_fin_result without obj_fin_logprior");
+            DUN_REQUIRE(c->obj_fin_objective == DUN_OBJ_MLL || c->obj_fin_q_logits != nullptr,
+                        "dun_fc_forward: the variational objective needs obj_fin_q_logits");
+            p.fin_result = c->obj_fin_result; p.fin_sums = c->obj_fin_sums; p.fin_q_logits = c->obj_fin_q_logits;
+            p.fin_logprior = c->obj_fin_logprior; p.fin_prior_ll = c->obj_fin_prior_ll;
+            p.fin_N = c->obj_fin_N_train; p.fin_batch = c->obj_fin_batch; p.fin_beta = c->obj_fin_beta;
+            p.fin_eps = c->obj_fin_eps; p.fin_objective = c->obj_fin_objective;
+        }
+    }
+    const dim3 grid(p.P), block(PN_T);
+#define PN_FWD(N)                                                                                   \
+    case N:                                                                                         \
+        if (c->train) hipLaunchKernelGGL((pn_forward_kernel<N, true>), grid, block, 0, s, p);       \
+        else hipLaunchKernelGGL((pn_forward_kernel<N, false>), grid, block, 0, s, p);               \
+        break;
+    switch (pn_tiles(c->W)) { PN_FWD(2) PN_FWD(4) PN_FWD(7) PN_FWD(8) }
+#undef PN_FWD
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+int pn_backward_trunk(const dun_fc_ctx* c, float* dUall, hipStream_t s) {
+    PnBwdP p;
+    memset(&p, 0, sizeof(p));
+    p.B = c->B; p.W = c->W; p.L = c->L; p.residual = c->residual; p.P = pn_workgroups(c->B);
+    p.w = c->p.w; p.w_out = c->p.w_out; p.gamma = c->p.gamma;
+    p.Z = c->Z; p.bn_mean = c->bn_mean; p.bn_rstd = c->bn_rstd;
+    p.dact = c->dact; p.dU = dUall; p.G = c->G;
+    p.dgamma = c->g.gamma; p.dbeta = c->g.beta;
+    p.sync = c->sync; p.sync_bytes = (int)pn_sync_bytes(c->B, c->W);
+    const dim3 grid(p.P), block(PN_T);
+#define PN_BWD(N) case N: hipLaunchKernelGGL((pn_backward_kernel<N>), grid, block, 0, s, p); break;
+    switch (pn_tiles(c->W)) { PN_BWD(2) PN_BWD(4) PN_BWD(7) PN_BWD(8) }
+#undef PN_BWD
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+}  // namespace dun
+
+using namespace dun;
+
+extern "C" int dun_fc_small_net_mode(int mode) {
+    const int prev = small_net_mode();
+    if (mode >= 0 && mode <= 2) g_small_net_mode = mode;
+    return prev;
+}
+
+extern "C" size_t dun_fc_sync_bytes(int B, int W) { return pn_sync_bytes(B, W); }
+
+extern "C" int dun_fc_sync_status(const dun_fc_ctx* c, dun_stream_t stream) {
+    if (c == nullptr || c->sync == nullptr) return 0;
+    unsigned code = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(&code, c->sync + 1, sizeof(code), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    return (int)code;
+}

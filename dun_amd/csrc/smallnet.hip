@@ -54,10 +54,10 @@ constexpr size_t SN_OFF_RBUF = SN_OFF_XBUF + (size_t)8 * SN_T * 8;
 constexpr size_t SN_OFF_OBUF = SN_OFF_RBUF + (size_t)SN_WAVES * 4 * 128 * 4;
 static inline size_t sn_lds(int B) { return SN_OFF_OBUF + (size_t)B * 16; }
 
-static const bool g_sn_off = getenv("DUN_SMALLNET") != nullptr && getenv("DUN_SMALLNET")[0] == '0';
+int small_net_mode();  // persist.hip: 0 tiled path, 1 these kernels, 2 the one-launch kernels (dun_fc_small_net_mode)
 
+// shape rule only (it sizes the workspace, which must not depend on the mode a later call runs in)
 bool sn_shape_ok(int B, int W) {
-    if (g_sn_off) return false;
     return W >= 4 && W <= SN_MAX_W && (W & 3) == 0 && B >= 1 && B <= SN_MAX_B;
 }
 size_t sn_extra_ws_floats(int B, int W, int L) { return sn_shape_ok(B, W) ? (size_t)L * B * W : 0; }
@@ -178,6 +178,7 @@ struct SnFwdP {
     float* rstd;        // [W] train: 1/sqrt(var+eps) out
     float* running_mean;
     float* running_var;
+    long long* nbt;     // this block's nn.BatchNorm1d.num_batches_tracked, or NULL
     int B, W, train, residual;
     float eps, momentum;
     double count, inv_count, unbias;  // rows, 1/rows, rows/(rows-1)
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(SN_T) void sn_block_fwd_kernel(SnFwdP p) {
             *reinterpret_cast<f32x4*>(p.rstd + c0) = o_rstd;
             *reinterpret_cast<f32x4*>(p.running_mean + c0) = o_rm;
             *reinterpret_cast<f32x4*>(p.running_var + c0) = o_rv;
+            if (p.nbt && blockIdx.x == 0) p.nbt[0] += 1;
         }
     } else {
 #pragma unroll
@@ -547,7 +549,20 @@ struct SnDwP {
     const float* H;   // [L(+1),B,W]
     float* dW;        // [L,W,W]
     float* db;        // [L,W]
-    int B, W;
+    int B, W, L;
+    // blockIdx.y == L (one-launch backward only): the input layer, dW_in = G^T x, db_in = sum_b G
+    const float* G;   // [B,W]
+    const float* x;   // [B,din]
+    float* dw_in;     // [W,din]
+    float* db_in;     // [W]
+    int din, vec_in;
+    // blockIdx.y == L + 1 (one-launch backward, head gradients accumulated by the forward): dw_out, db_out from the
+    // per-workgroup partial sums [P][W], [P]
+    const float* dwpart;
+    const float* dbpart;
+    float* dw_out;
+    float* db_out;
+    int P;
 };
 __global__ __launch_bounds__(SN_T) void sn_dw_batched_kernel(SnDwP p) {
     extern __shared__ __attribute__((aligned(16))) char sn_smem[];
@@ -555,10 +570,30 @@ __global__ __launch_bounds__(SN_T) void sn_dw_batched_kernel(SnDwP p) {
     float* obuf = reinterpret_cast<float*>(sn_smem + SN_OFF_OBUF);
     const int c0 = blockIdx.x * SN_NC, i = blockIdx.y;
     const size_t plane = (size_t)p.B * p.W;
-    const float* dU = p.dU + (size_t)i * plane + c0;
+    if (i == p.L + 1) {  // fp64, fixed order
+        const int t = threadIdx.x;
+        if (t < SN_NC) {
+            double a = 0.0;
+            for (int q = 0; q < p.P; ++q) a += (double)p.dwpart[(size_t)q * p.W + c0 + t];
+            p.dw_out[c0 + t] = (float)a;
+        } else if (t == 64 && blockIdx.x == 0) {
+            double a = 0.0;
+            for (int q = 0; q < p.P; ++q) a += (double)p.dbpart[q];
+            p.db_out[0] = (float)a;
+        }
+        return;
+    }
+    const float* dU = (i == p.L ? p.G : p.dU + (size_t)i * plane) + c0;
     for (int r = threadIdx.x; r < p.B; r += SN_T)
         *reinterpret_cast<f32x4*>(obuf + 4 * r) = *reinterpret_cast<const f32x4*>(dU + (size_t)r * p.W);
     __syncthreads();
+    if (i == p.L) {
+        if (p.vec_in)
+            sn_dw_phase<4>(obuf, rbuf, p.x, p.din, p.din, p.B, p.dw_in, p.db_in, c0);
+        else
+            sn_dw_phase<1>(obuf, rbuf, p.x, p.din, p.din, p.B, p.dw_in, p.db_in, c0);
+        return;
+    }
     sn_dw_phase<4>(obuf, rbuf, p.H + (size_t)i * plane, p.W, p.W, p.B, p.dW + (size_t)i * p.W * p.W, p.db + (size_t)i * p.W, c0);
 }
 
@@ -622,7 +657,7 @@ static inline bool sn_al16(const void* p) { return (reinterpret_cast<uintptr_t>(
 
 // may this context run on the column-owned kernels?  (shape rule + 16-byte alignment of everything touched in vectors)
 bool sn_eligible(const dun_fc_ctx* c, bool backward) {
-    if (!sn_shape_ok(c->B, c->W)) return false;
+    if (small_net_mode() == 0 || !sn_shape_ok(c->B, c->W)) return false;
     if (c->depth == 0 && !backward) return false;
     bool ok = sn_al16(c->H) && sn_al16(c->p.w) && sn_al16(c->p.b) && sn_al16(c->p.gamma) && sn_al16(c->p.beta) &&
               sn_al16(c->running_mean) && sn_al16(c->running_var) && (!c->train || sn_al16(c->Z));
@@ -649,6 +684,7 @@ int sn_forward_block(const dun_fc_ctx* c, int i, hipStream_t s) {
     p.rstd = c->train ? c->bn_rstd + (size_t)i * W : nullptr;
     p.running_mean = c->running_mean + (size_t)i * W;
     p.running_var = c->running_var + (size_t)i * W;
+    p.nbt = (c->train && c->num_batches_tracked) ? reinterpret_cast<long long*>(c->num_batches_tracked) + i : nullptr;
     p.B = B; p.W = W; p.train = c->train; p.residual = c->residual;
     p.eps = c->bn_eps; p.momentum = c->bn_momentum; p.count = (double)B;
     p.inv_count = 1.0 / (double)B; p.unbias = B > 1 ? (double)B / ((double)B - 1.0) : 1.0;
@@ -702,13 +738,35 @@ int sn_backward_blocks(const dun_fc_ctx* c, float* dUall, hipStream_t s) {
     }
     if (L > 0) {
         SnDwP q;
-        q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W;
+        memset(&q, 0, sizeof(q));
+        q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W; q.L = L;
         const size_t lds = sn_lds(B);
         int rc = sn_allow_lds(sn_dw_batched_kernel, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(sn_dw_batched_kernel, dim3(W / SN_NC, L), dim3(SN_T), lds, s, q);
         DUN_LAUNCH_CHECK();
     }
+    return DUN_OK;
+}
+
+// Weight gradients of the one-launch backward (persist.hip): every block, the input layer and -- when the forward
+// accumulated them -- the head's partial sums, in ONE launch of grid (W/4, L + 1 or L + 2).
+int sn_dw_all(const dun_fc_ctx* c, const float* dUall, bool head_from_forward, hipStream_t s) {
+    const int W = c->W, B = c->B, L = c->L;
+    SnDwP q;
+    memset(&q, 0, sizeof(q));
+    q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W; q.L = L;
+    q.G = c->G; q.x = c->x; q.dw_in = c->g.w_in; q.db_in = c->g.b_in; q.din = c->din;
+    q.vec_in = ((c->din & 3) == 0 && sn_al16(c->x) && sn_al16(c->g.w_in)) ? 1 : 0;
+    if (head_from_forward) {
+        q.dwpart = c->obj_dwpart; q.dbpart = c->obj_dbpart; q.dw_out = c->g.w_out; q.db_out = c->g.b_out;
+        q.P = (B + 15) / 16;
+    }
+    const size_t lds = sn_lds(B);
+    int rc = sn_allow_lds(sn_dw_batched_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sn_dw_batched_kernel, dim3(W / SN_NC, L + (head_from_forward ? 2 : 1)), dim3(SN_T), lds, s, q);
+    DUN_LAUNCH_CHECK();
     return DUN_OK;
 }
 

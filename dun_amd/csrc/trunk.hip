@@ -28,6 +28,11 @@ size_t sn_extra_ws_floats(int B, int W, int L);
 bool sn_eligible(const dun_fc_ctx* c, bool backward);
 int sn_forward_block(const dun_fc_ctx* c, int i, hipStream_t s);
 int sn_backward_blocks(const dun_fc_ctx* c, float* dUall, hipStream_t s);
+int sn_dw_all(const dun_fc_ctx* c, const float* dUall, bool head_from_forward, hipStream_t s);
+// persist.hip: the whole forward / the whole backward of a small net in ONE launch each (row-owning workgroups)
+bool pn_eligible(const dun_fc_ctx* c);
+int pn_forward(const dun_fc_ctx* c, hipStream_t s);
+int pn_backward_trunk(const dun_fc_ctx* c, float* dUall, hipStream_t s);
 
 // rows per column-reduction partial: 128, or 32 for small batches (four times the workgroups, a quarter of the serial
 // row loop: the UCI-sized nets are latency bound)
@@ -93,8 +98,9 @@ __global__ __launch_bounds__(256) void reduce_cols_kernel(const PT* __restrict__
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums, int W, double count,
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var) {
+                                                          float* __restrict__ running_var, long long* nbt) {
     const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;  // nn.BatchNorm1d.num_batches_tracked of this block
     if (c >= W) return;
     const double m = sums[c] / count;
     double var = sums[W + c] / count - m * m;
@@ -113,8 +119,9 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* _
                                                                  double* __restrict__ sums, float* __restrict__ mean,
                                                                  float* __restrict__ rstd,
                                                                  float* __restrict__ running_mean,
-                                                                 float* __restrict__ running_var) {
+                                                                 float* __restrict__ running_var, long long* nbt) {
     __shared__ double red[2][RCY][RCX];
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;
     const int tx = threadIdx.x & (RCX - 1), ty = threadIdx.x / RCX;
     const int c = blockIdx.x * RCX + tx;
     double s1 = 0.0, s2 = 0.0;
@@ -717,8 +724,11 @@ static int check_ctx(const dun_fc_ctx* c, const char* who) {
 }
 
 static inline int obj_nparts(int B) {
-    const int n = ceil_div(B, 32);  // four wavefronts per workgroup: >= 8 rows per wavefront up to 512 workgroups
-    return n < 1 ? 1 : (n > 512 ? 512 : n);
+    // up to 2048 rows: one partial per 16 rows -- the row-owning workgroups of the one-launch forward (persist.hip) write
+    // the same [depth][nparts] layout; beyond: four wavefronts per workgroup, >= 8 rows per wavefront up to 512 workgroups
+    if (B <= 2048) return B < 1 ? 1 : ceil_div(B, 16);
+    const int n = ceil_div(B, 32);
+    return n > 512 ? 512 : n;
 }
 
 static bool head_fused(const dun_fc_ctx* c);
@@ -834,15 +844,16 @@ static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream
                     global_batch);
         float* m = c->bn_mean + (size_t)i * W;
         float* r = c->bn_rstd + (size_t)i * W;
+        long long* nbt = c->num_batches_tracked ? reinterpret_cast<long long*>(c->num_batches_tracked) + i : nullptr;
         if (from_partials)
             hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(ceil_div(W, RCX)), dim3(256), 0, s,
                                reinterpret_cast<const double*>(c->ws), gemm_colstat_tiles(B, W), W, global_batch,
                                c->bn_eps, c->bn_momentum, c->bn_sums, m, r, c->running_mean + (size_t)i * W,
-                               c->running_var + (size_t)i * W);
+                               c->running_var + (size_t)i * W, nbt);
         else
             hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(W, 256)), dim3(256), 0, s, c->bn_sums, W, global_batch,
                                c->bn_eps, c->bn_momentum, m, r, c->running_mean + (size_t)i * W,
-                               c->running_var + (size_t)i * W);
+                               c->running_var + (size_t)i * W, nbt);
         DUN_LAUNCH_CHECK();
         mean = m; stat = r; is_var = 0;
     } else {
@@ -1130,6 +1141,14 @@ extern "C" int dun_fc_obj_num_partials(int B, int O) { return (B > 0 && O == 1) 
 
 extern "C" int dun_fc_head_is_fused(const dun_fc_ctx* c) { return (c != nullptr && head_fused(c)) ? 1 : 0; }
 
+extern "C" int dun_fc_head_grads_in_forward(const dun_fc_ctx* c) {
+    return (c != nullptr && c->train && c->O == 1 && (head_fused(c) || pn_eligible(c))) ? 1 : 0;
+}
+
+extern "C" int dun_fc_objective_in_forward(const dun_fc_ctx* c) {
+    return (c != nullptr && c->obj_y && c->obj_fin_result && c->O == 1 && pn_eligible(c)) ? 1 : 0;
+}
+
 extern "C" size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L) {
     (void)din;
     const size_t wT = dx_transposed(B, W, L) ? (size_t)L * W * W : 0;
@@ -1169,6 +1188,7 @@ extern "C" int dun_fc_head_depth(const dun_fc_ctx* c, int d, dun_stream_t stream
 extern "C" int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream) {
     int rc = check_ctx(c, "dun_fc_forward");
     if (rc) return rc;
+    if (pn_eligible(c)) return pn_forward(c, STREAM);  // small net, one output: the whole forward in one launch
     if ((rc = input_layer(c, STREAM))) return rc;
     if (sn_eligible(c, false)) {  // small net: one column-owned launch per block
         for (int i = 0; i < c->depth; ++i)
@@ -1220,6 +1240,17 @@ extern "C" int dun_fc_bwd_end(const dun_fc_ctx* c, dun_stream_t stream) {
 extern "C" int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream) {
     int rc = check_bwd(c, "dun_fc_backward");
     if (rc) return rc;
+    if (pn_eligible(c)) {  // small net, one output: one launch for the trunk, one for every weight gradient
+        float* dUall = c->ws + base_workspace_floats(c->B, c->W, c->O, c->L);
+        const bool from_fwd = c->head_grads_from_forward != 0;
+        if (from_fwd)
+            DUN_REQUIRE(c->obj_dwpart && c->obj_dbpart, "dun_fc_backward: head_grads_from_forward without the forward's partial sums");
+        else if ((rc = head_backward(c->H, c->p.w_out, c->dact, (c->depth + 1) * c->B, c->W, c->O, c->g.w_out, c->g.b_out,
+                                     nullptr, c->ws, c->ws_floats, STREAM)))
+            return rc;
+        if ((rc = pn_backward_trunk(c, dUall, STREAM))) return rc;
+        return sn_dw_all(c, dUall, from_fwd, STREAM);
+    }
     if (sn_eligible(c, true)) {  // small net: head gradients, then one column-owned launch per block + input layer
         const int rows = (c->depth + 1) * c->B;
         if ((rc = head_backward(c->H, c->p.w_out, c->dact, rows, c->W, c->O, c->g.w_out, c->g.b_out, nullptr, c->ws,
@@ -1252,6 +1283,77 @@ extern "C" int dun_sgd_step(float* p, const float* g, float* buf, size_t n, floa
     if (blocks < 1) blocks = 1;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, p, g, buf, n, lr, momentum, weight_decay);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+// ---- the same update over several tensors in one launch ----------------------------------------------------------------
+namespace dun {
+struct SgdSegs {
+    dun_sgd_segment seg[DUN_SGD_MAX_SEGMENTS];
+    int nseg;
+};
+// grid (workgroups per segment, segments); element by element (any alignment), the arithmetic of sgd_kernel
+__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdSegs a, float lr, float momentum, float wd) {
+    const dun_sgd_segment sg = a.seg[blockIdx.y];
+    float* __restrict__ p = sg.p;
+    const float* __restrict__ g = sg.g;
+    float* __restrict__ buf = sg.buf;
+    const size_t n = sg.n;
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf)) & 15) == 0) {
+        const size_t n4 = n / 4;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+            const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+            f32x4 bv = reinterpret_cast<f32x4*>(buf)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = gv[e] + wd * pv[e];
+                bv[e] = momentum * bv[e] + ge;
+                pv[e] -= lr * bv[e];
+            }
+            reinterpret_cast<f32x4*>(buf)[i] = bv;
+            reinterpret_cast<f32x4*>(p)[i] = pv;
+        }
+        const size_t i = n4 * 4 + threadIdx.x;
+        if (blockIdx.x == 0 && i < n) {
+            const float ge = g[i] + wd * p[i];
+            const float b = momentum * buf[i] + ge;
+            buf[i] = b;
+            p[i] -= lr * b;
+        }
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float ge = g[i] + wd * p[i];
+        const float b = momentum * buf[i] + ge;
+        buf[i] = b;
+        p[i] -= lr * b;
+    }
+}
+}  // namespace dun
+
+extern "C" int dun_sgd_step_multi(const dun_sgd_segment* segments, int nseg, float lr, float momentum, float weight_decay,
+                                  dun_stream_t stream) {
+    DUN_REQUIRE(nseg >= 0 && nseg <= DUN_SGD_MAX_SEGMENTS, "dun_sgd_step_multi: %d segments (at most %d)", nseg,
+                DUN_SGD_MAX_SEGMENTS);
+    DUN_REQUIRE(nseg == 0 || segments != nullptr, "dun_sgd_step_multi: null segments");
+    SgdSegs a;
+    memset(&a, 0, sizeof(a));
+    size_t nmax = 0;
+    for (int k = 0; k < nseg; ++k) {
+        DUN_REQUIRE(segments[k].n == 0 || (segments[k].p && segments[k].g && segments[k].buf),
+                    "dun_sgd_step_multi: null pointer in segment %d", k);
+        if (segments[k].n == 0) continue;
+        a.seg[a.nseg++] = segments[k];
+        if (segments[k].n > nmax) nmax = segments[k].n;
+    }
+    if (a.nseg == 0) return DUN_OK;
+    size_t blocks = (nmax / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)blocks, (unsigned)a.nseg), dim3(256), 0, STREAM, a, lr, momentum,
+                       weight_decay);
     DUN_LAUNCH_CHECK();
     return DUN_OK;
 }

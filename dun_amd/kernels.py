@@ -48,6 +48,14 @@ class FcBuffers(object):
         c.H, c.Z = L.f32(self.H), (L.f32(self.Z) if self.Z.numel() else None)
         c.bn_mean, c.bn_rstd, c.bn_sums = L.f32(self.bn_mean), L.f32(self.bn_rstd), L.ptr(self.bn_sums)
         c.ws, c.ws_floats = L.f32(self.ws), n_ws
+        # nn.BatchNorm1d.num_batches_tracked is advanced by the kernels that update the running statistics
+        nbt = getattr(model, "num_batches_tracked", None)
+        c.num_batches_tracked = nbt.data_ptr() if (nbt is not None and nbt.numel() and nbt.is_cuda) else None
+        # hand-off words of the one-launch small-net kernels: zeroed once here, owned by the kernels afterwards
+        n_sync = L.lib().dun_fc_sync_bytes(B, W)
+        self.sync = torch.zeros(n_sync // 4, device=dev, dtype=torch.int32) if n_sync else None
+        if self.sync is not None:
+            c.sync, c.sync_bytes = L.ptr(self.sync), n_sync
         self.c = c
 
     def new_act(self):
@@ -80,6 +88,7 @@ class FcBuffers(object):
         c = self.c
         c.obj_dwpart = c.obj_dbpart = None
         c.head_grads_from_forward = 0
+        c.obj_fin_result = c.obj_fin_sums = c.obj_fin_q_logits = c.obj_fin_logprior = c.obj_fin_prior_ll = None
         if spec is None:
             c.obj_y = c.obj_w = c.obj_log_std = c.obj_dact = c.obj_partials = None
             self._obj = None
@@ -97,7 +106,24 @@ class FcBuffers(object):
         c.obj_dact = None if spec.dact is None else L.f32(spec.dact)
         c.obj_partials = L.ptr(spec.partials)
         self._obj = spec  # keeps the tensors behind the raw pointers alive until the next forward
-        if spec.dact is not None and self.train and self.head_fused and os.environ.get("DUN_HEAD_DW_IN_FORWARD", "1") != "0":
+        fin = getattr(spec, "fin", None)
+        spec.res = spec.sums = None
+        if fin is not None:
+            # where the forward is ONE launch (small nets) the workgroup that delivers the last partial sums also runs
+            # the depth-level finalisation: the step needs no dun_depth_finalize_partials launch
+            spec.res = torch.empty(L.res_floats(D), device=dev, dtype=torch.float32)
+            spec.sums = torch.empty(D, device=dev, dtype=torch.float64)
+            c.obj_fin_result, c.obj_fin_sums = L.f32(spec.res), L.ptr(spec.sums)
+            c.obj_fin_q_logits = None if fin["q_logits"] is None else L.f32(fin["q_logits"])
+            c.obj_fin_logprior = L.f32(fin["logprior"])
+            c.obj_fin_prior_ll = None
+            c.obj_fin_N_train, c.obj_fin_batch = float(fin["N_train"]), float(fin["batch"])
+            c.obj_fin_beta, c.obj_fin_eps, c.obj_fin_objective = float(fin["beta"]), float(fin["eps"]), int(fin["objective"])
+            if not L.lib().dun_fc_objective_in_forward(C.byref(c)):
+                c.obj_fin_result = c.obj_fin_sums = c.obj_fin_q_logits = c.obj_fin_logprior = None
+                spec.res = spec.sums = None
+        if spec.dact is not None and self.train and os.environ.get("DUN_HEAD_DW_IN_FORWARD", "1") != "0" \
+                and L.lib().dun_fc_head_grads_in_forward(C.byref(c)):
             # the head's weight / bias gradient is accumulated by the forward's head kernels (per-workgroup partials,
             # kept with the buffers: [D, nparts, W] floats, 214 MB at the wide configuration)
             if self._dwpart is None:
@@ -238,6 +264,25 @@ class HipBackend(object):
                                         None if metrics is None else L.ptr(metrics), s), "dun_predict_softmax")
         return probs, None, metrics
 
+    def predict_step(self, act, q_logits, y, log_std, objective, out):
+        """End of a regression training step in ONE launch: depth-marginal mean / std of `act` under q = softmax(q_logits)
+        (the post-step q(d)), the metric sums, q itself and the step's objective.  `out`: double [3] receiving
+        [objective, nll_sum, squared-error sum].  -> q (float [D]).  Falls back to None for batches that need the
+        two-stage metric reduction."""
+        lib = L.lib()
+        D, n = act.shape[0], act[0].numel()
+        if lib.dun_predict_num_partials(n, 1) != 1 or q_logits.numel() != D:
+            return None
+        dev = act.device
+        mean = torch.empty(n, device=dev, dtype=torch.float32)
+        std = torch.empty(n, device=dev, dtype=torch.float32)
+        q = torch.empty(D, device=dev, dtype=torch.float32)
+        m = out[1:]
+        L.check(lib.dun_predict_gauss_step(L.f32(act), L.f32(q_logits), 1, D, n, L.f32(mean), L.f32(std), L.f32(y),
+                                           L.f32(log_std), L.ptr(m), L.ptr(m), L.f32(q), L.f32(objective), L.ptr(out),
+                                           L.stream_ptr(dev)), "dun_predict_gauss_step")
+        return q
+
     # ---- trunk ----------------------------------------------------------------------------------------
     def fc_buffers(self, model, B, depth, train):
         return FcBuffers(model, B, depth, train)
@@ -315,6 +360,17 @@ class HipBackend(object):
     def sgd_step(self, p, g, buf, lr, momentum, weight_decay):
         L.check(L.lib().dun_sgd_step(L.f32(p), L.f32(g), L.f32(buf), p.numel(), float(lr), float(momentum),
                                      float(weight_decay), L.stream_ptr(p.device)), "dun_sgd_step")
+
+    def sgd_step_multi(self, triples, lr, momentum, weight_decay):
+        """The same update over several (param, grad, momentum buffer) triples, DUN_SGD_MAX_SEGMENTS per launch."""
+        lib = L.lib()
+        for k in range(0, len(triples), L.SGD_MAX_SEGMENTS):
+            chunk = triples[k:k + L.SGD_MAX_SEGMENTS]
+            segs = (L.SgdSegment * len(chunk))()
+            for sg, (p, g, b) in zip(segs, chunk):
+                sg.p, sg.g, sg.buf, sg.n = L.f32(p), L.f32(g), L.f32(b), p.numel()
+            L.check(lib.dun_sgd_step_multi(segs, len(chunk), float(lr), float(momentum), float(weight_decay),
+                                           L.stream_ptr(chunk[0][0].device)), "dun_sgd_step_multi")
 
     # ---- raw GEMM (tests / benchmarks) ----------------------------------------------------------------
     def gemm(self, A, B, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, relu=False, R=None, U=None, V=None,

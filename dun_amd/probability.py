@@ -80,11 +80,15 @@ class HeadObjective(object):
     is in a register when it is written, so y - act, d loss / d act and the per-depth sums of squared residuals cost
     no further pass over act_vec).  The forward fills ``partials`` (double [D, nparts]) and, when depth weights were
     given, ``dact`` ([D,B,1]); ``_fused(..., head_pass=spec)`` then skips its own streaming pass."""
-    __slots__ = ("y", "w", "w_is_logits", "log_std", "inv_batch", "partials", "dact")
+    __slots__ = ("y", "w", "w_is_logits", "log_std", "inv_batch", "partials", "dact", "fin", "res", "sums")
 
-    def __init__(self, y, w, w_is_logits, log_std, inv_batch):
+    def __init__(self, y, w, w_is_logits, log_std, inv_batch, fin=None):
         self.y, self.w, self.w_is_logits, self.log_std, self.inv_batch = y, w, w_is_logits, log_std, inv_batch
         self.partials = self.dact = None
+        # fin: the depth-level arguments of the objective (dict: objective, q_logits, logprior, N_train, batch, beta, eps).
+        # A trunk whose forward is one launch finishes the objective there and leaves the result block in `res` (and the
+        # per-depth sums in `sums`); otherwise both stay None and _fused launches the finalisation itself.
+        self.fin, self.res, self.sums = fin, None, None
 
 
 class FusedOut(object):
@@ -109,8 +113,10 @@ class FusedOut(object):
     loglike_sum = property(lambda s: s._arr(4))  # sum_b loglike[d,b]
 
 
-def head_objective_spec(y, f_neg_loglike, objective, q_logits, batch, dist=None, want_grad=True):
-    """A HeadObjective for this step, or None where the fusion does not apply (classification; more than one output)."""
+def head_objective_spec(y, f_neg_loglike, objective, q_logits, batch, dist=None, want_grad=True, finalize=None):
+    """A HeadObjective for this step, or None where the fusion does not apply (classification; more than one output).
+    ``finalize`` (dict: logprior, N_train, beta, eps; single-device jobs without a weight prior) also asks the forward
+    to finish the objective where it can."""
     if not isinstance(f_neg_loglike, homo_Gauss_mloglike) or f_neg_loglike.log_std.numel() != 1:
         return None
     if y.dim() > 2 or (y.dim() == 2 and y.shape[1] != 1) or y.shape[0] != batch:
@@ -118,7 +124,13 @@ def head_objective_spec(y, f_neg_loglike, objective, q_logits, batch, dist=None,
     gb = batch if dist is None else dist.global_batch(batch)
     yy = y.detach().to(torch.float32).contiguous()
     w = q_logits.detach() if (objective == OBJ_VI and want_grad) else None
-    return HeadObjective(yy, w, True, f_neg_loglike.log_std.detach(), 1.0 / gb)
+    fin = None
+    if finalize is not None and dist is None:
+        fin = dict(objective=objective, q_logits=None if q_logits is None else q_logits.detach(),
+                   logprior=finalize["logprior"].to(device=yy.device, dtype=torch.float32).contiguous(),
+                   N_train=float(finalize["N_train"]), batch=float(gb), beta=float(finalize.get("beta", 1.0)),
+                   eps=float(finalize.get("eps", 1e-35)))
+    return HeadObjective(yy, w, True, f_neg_loglike.log_std.detach(), 1.0 / gb, fin)
 
 
 def _fused(act_vec, y, f_neg_loglike, N_train, logprior, prior_loglikes, objective, q_logits=None, beta=1.0,
@@ -143,14 +155,26 @@ def _fused(act_vec, y, f_neg_loglike, N_train, logprior, prior_loglikes, objecti
     # partials are added up inside the finalisation launch, so the whole objective is two launches
     local = dist is None
 
+    # the trunk's head kernels already ran the pass (HeadObjective): its partial sums (and dact) are used as they are
+    from_head = head_pass is not None and head_pass.partials is not None and regression and not want_ll
+    # ... and, where the whole forward was one launch, the depth-level finalisation too (head_pass.res): taken only if it
+    # was computed from the very arguments of this call
+    done = None
+    if from_head and head_pass.res is not None and local and prior is None:
+        f = head_pass.fin
+        same_q = ql is None or (f["q_logits"] is not None and f["q_logits"].data_ptr() == ql.data_ptr())
+        if (f["objective"] == objective and f["N_train"] == float(N_train) and f["beta"] == float(beta)
+                and f["eps"] == float(eps) and f["batch"] == float(gb) and same_q
+                and f["logprior"].data_ptr() == logprior.contiguous().data_ptr()):
+            done = head_pass
+
     def finalize(s_, q_, obj):
+        if done is not None:
+            return done.res, done.sums
         if local:
             return be.depth_finalize(s_, regression, q_, logprior, prior, ls, N_train, gb, beta, eps, obj, partials=True)
         dist.all_reduce(s_)
         return be.depth_finalize(s_, regression, q_, logprior, prior, ls, N_train, gb, beta, eps, obj), s_
-
-    # the trunk's head kernels already ran the pass (HeadObjective): its partial sums (and dact) are used as they are
-    from_head = head_pass is not None and head_pass.partials is not None and regression and not want_ll
 
     def head_sums():
         return head_pass.partials if local else be.ll_reduce(head_pass.partials)
@@ -287,9 +311,11 @@ class depth_categorical(nn.Module):
         return _fused(act_vec, y, f_neg_loglike, N_train, self.logprior, prior_loglikes, OBJ_MLL,
                       want_grad=want_grad, dist=self._dist, want_ll=want_ll, head_pass=head_pass)
 
-    def head_objective(self, y, f_neg_loglike, batch, want_grad=True):
-        """HeadObjective for the exact-marginal objective (sums only: the posterior is not known before the pass)."""
-        return head_objective_spec(y, f_neg_loglike, OBJ_MLL, None, batch, self._dist, want_grad)
+    def head_objective(self, y, f_neg_loglike, batch, want_grad=True, N_train=None):
+        """HeadObjective for the exact-marginal objective (sums only: the posterior is not known before the pass).
+        With ``N_train`` the forward may also finish the objective (no weight prior, one device)."""
+        fin = None if N_train is None else dict(logprior=self.logprior, N_train=N_train)
+        return head_objective_spec(y, f_neg_loglike, OBJ_MLL, None, batch, self._dist, want_grad, fin)
 
 
 class _Elbo(torch.autograd.Function):
@@ -359,9 +385,11 @@ class depth_categorical_VI(depth_categorical):
                       q_logits=self.q_logits, beta=Beta, eps=self.eps, want_grad=want_grad, dist=self._dist,
                       want_ll=want_ll, head_pass=head_pass)
 
-    def head_objective(self, y, f_neg_loglike, batch, want_grad=True):
-        """HeadObjective for the ELBO: q is known before the pass, so the head kernels also write d loss / d act."""
-        return head_objective_spec(y, f_neg_loglike, OBJ_VI, self.q_logits, batch, self._dist, want_grad)
+    def head_objective(self, y, f_neg_loglike, batch, want_grad=True, N_train=None, Beta=1):
+        """HeadObjective for the ELBO: q is known before the pass, so the head kernels also write d loss / d act.
+        With ``N_train`` the forward may also finish the objective (no weight prior, one device)."""
+        fin = None if N_train is None else dict(logprior=self.logprior, N_train=N_train, beta=Beta, eps=self.eps)
+        return head_objective_spec(y, f_neg_loglike, OBJ_VI, self.q_logits, batch, self._dist, want_grad, fin)
 
     def q_predict(self, act_vec, depth=None, softmax=False):
         return depth_categorical.marginalise_d_predict(act_vec, self.get_q_probs(), depth=depth, softmax=softmax)

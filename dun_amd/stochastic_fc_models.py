@@ -265,8 +265,8 @@ class arq_uncert_fc_resnet(nn.Module):
                 be.fc_block_norm(buf, i, gb)
             if not fused:
                 be.fc_head_depth(buf, depth)
-        if train and depth > 0:
-            self.num_batches_tracked[:depth] += 1
+        # (nn.BatchNorm1d.num_batches_tracked of the blocks that ran is advanced by the kernels that update the running
+        # statistics: dun_fc_ctx.num_batches_tracked)
         return buf
 
     def _run_backward(self, buf, dact):

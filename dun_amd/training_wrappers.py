@@ -103,10 +103,22 @@ class DUN(BaseNet):
             for g, r in zip(loose, torch._utils._unflatten_dense_tensors(flat, loose)):
                 g.copy_(r)
 
-    def _metrics_device(self, act_vec, y, objective):
-        """Device side of the returned scalars: ([objective,] nll_sum, err_sum) as one fp64 tensor + the divisor."""
+    def _metrics_device(self, act_vec, y, objective, q_logits=None):
+        """Device side of the returned scalars: ([objective,] nll_sum, err_sum) as one fp64 tensor + the divisor.
+        ``q_logits`` (DUN_VI.fit): the metrics use q = softmax(q_logits), which also becomes ``current_posterior``."""
         be = kernels.backend()
         act = act_vec.detach()
+        if q_logits is not None:
+            # regression on one device: predictor, metric sums, q(d) and the objective's copy in ONE launch
+            step = getattr(be, "predict_step", None)
+            if step is not None and self.regression and self._dist is None and objective is not None:
+                out = torch.empty(3, device=act.device, dtype=torch.float64)
+                q = step(act, q_logits.detach(), y.to(torch.float32).contiguous(), self.f_neg_loglike.log_std.detach(),
+                         objective.detach().reshape(1), out)
+                if q is not None:
+                    self.prob_model.current_posterior = q
+                    return out, act[0].numel()
+            self.prob_model.current_posterior = self.prob_model.get_q_probs().detach()
         post = self.prob_model.current_posterior
         # [objective,] nll_sum, err_sum[, bad_labels] in ONE fp64 tensor: the kernel writes its sums straight into it
         # (classification carries a third sum: the number of labels outside [0,C) other than the ignored -100)
@@ -218,19 +230,23 @@ class DUN(BaseNet):
             return None
         return self.model.get_w_prior_loglike(k=None)
 
-    def _forward_with_objective(self, x, y, want_grad=True):
+    def _forward_with_objective(self, x, y, want_grad=True, finalize=False):
         """model.forward(x), with the likelihood pass folded into the trunk's head kernels where that applies
-        (regression on an FC trunk): -> (act_vec, HeadObjective or None)."""
+        (regression on an FC trunk): -> (act_vec, HeadObjective or None).  ``finalize`` (a training step of a net
+        without a weight prior): a trunk whose forward is one launch may finish the objective there as well."""
         spec = None
         if self.regression and getattr(self.model, "supports_head_objective", False):
-            spec = self.prob_model.head_objective(y, self.f_neg_loglike, x.shape[0], want_grad)
+            if finalize and getattr(self.model, "w_prior", 0) is None:
+                spec = self.prob_model.head_objective(y, self.f_neg_loglike, x.shape[0], want_grad, N_train=self.N_train)
+            else:
+                spec = self.prob_model.head_objective(y, self.f_neg_loglike, x.shape[0], want_grad)
         if spec is None:
             return self.model.forward(x), None
         return self.model.forward(x, objective=spec), spec
 
     def _step(self, x, y):
         self.optimizer.zero_grad()
-        act_vec, head_pass = self._forward_with_objective(x, y)
+        act_vec, head_pass = self._forward_with_objective(x, y, finalize=True)
         prior_loglikes = self._prior_loglikes()
         out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train,
                                               head_pass=head_pass)
@@ -350,14 +366,14 @@ class DUN_VI(DUN):
 
     def _step(self, x, y):
         self.optimizer.zero_grad()
-        act_vec, head_pass = self._forward_with_objective(x, y)
+        act_vec, head_pass = self._forward_with_objective(x, y, finalize=True)
         prior_loglikes = self._prior_loglikes()
         out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train, Beta=1,
                                               head_pass=head_pass)
         self._backward(act_vec, prior_loglikes, out)
         self.optimizer.step()
-        self.prob_model.current_posterior = self.prob_model.get_q_probs().detach()
-        return self._metrics_device(act_vec, y, out.objective)
+        # train metrics with the POST-step q(d), which also becomes current_posterior (training_wrappers.py:229-242)
+        return self._metrics_device(act_vec, y, out.objective, q_logits=self.prob_model.q_logits)
 
     def fit(self, x, y):
         """Optimise the ELBO over weights and q(d)"""

@@ -129,6 +129,13 @@ int dun_elbo_gauss_static(const float* act, const float* y, const float* log_std
  *   sum_b (mean - y)^2.  Overwritten (no need to zero it); partials: double [2][dun_predict_num_partials(n, 1)]. */
 int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std, const float* y,
                       const float* log_std, double* partials, double* metrics, dun_stream_t stream);
+/* dun_predict_gauss for the end of a training step (src/DUN/training_wrappers.py:229-245): q may be given as logits
+ * (q_is_logits: q = softmax(q) is taken on device, F.softmax's fp32 arithmetic -- the post-step q(d) of DUN_VI.fit) and is
+ * then also written to q_out [D] (nullable); objective_src (nullable, float [1]: DUN_RES_OBJECTIVE of the step's result
+ * block) is copied to objective_dst (double [1]) so that everything fit() returns comes home in one tensor. */
+int dun_predict_gauss_step(const float* act, const float* q, int q_is_logits, int D, int n, float* mean, float* std,
+                           const float* y, const float* log_std, double* partials, double* metrics, float* q_out,
+                           const float* objective_src, double* objective_dst, dun_stream_t stream);
 /* Softmax: act [D,B,C] -> probs [B,C] = sum_d q_d softmax(act[d,b,:]).
  *   metrics (nullable, double [3]; needs y int64 [B]): sum_b -log probs[b,y_b], count(argmax != y), count of labels
  *   outside [0,C) other than -100.  y == -100 adds 0 to the first (nn.NLLLoss's ignore_index,
@@ -231,7 +238,7 @@ typedef struct dun_fc_ctx {
     float* obj_dact;          /* [depth+1,B] d(-objective/N)/d act, or NULL */
     double* obj_partials;     /* [depth+1, dun_fc_obj_num_partials(B, O)]: per-workgroup sums of (y - act)^2, the layout
                                  dun_ll_reduce / dun_depth_finalize_partials take */
-    /* Optional, with obj_w and where dun_fc_head_is_fused: the head's weight / bias gradient from the forward pass.
+    /* Optional, with obj_w and where dun_fc_head_grads_in_forward: the head's weight / bias gradient from the forward pass.
      * d loss / d act of a row is known as soon as its head value is, and the row of h is in registers then, so
      * sum_rows dact[row] * h[row,:] is accumulated there: per-workgroup partials [depth+1, P, W] and [depth+1, P],
      * P = dun_fc_obj_num_partials.  A backward whose `dact` IS the forward's obj_dact sets head_grads_from_forward and
@@ -240,6 +247,26 @@ typedef struct dun_fc_ctx {
     float* obj_dwpart;
     float* obj_dbpart;
     int head_grads_from_forward;
+    /* Optional: nn.BatchNorm1d's num_batches_tracked [L] (int64).  A train-mode forward adds 1 to the entries of the
+     * blocks it runs, inside the kernels that update the running statistics (torch: functional.batch_norm's caller,
+     * behind src/DUN/layers.py:38), instead of the host issuing one more launch per step. */
+    int64_t* num_batches_tracked;
+    /* Optional: hand-off words of the one-launch forward / backward of small nets (dun_fc_sync_bytes(B, W) bytes,
+     * 256-byte aligned, ZEROED ONCE by the caller when allocated and never touched by it afterwards; NULL: the
+     * one-launch kernels are not used).  One buffer per context; calls that share it must not overlap. */
+    uint32_t* sync;
+    size_t sync_bytes;
+    /* Optional, with obj_y: finish the objective inside the forward launch where dun_fc_objective_in_forward(c) says
+     * so -- the workgroup that delivers the last partial sums runs dun_depth_finalize_partials' arithmetic itself
+     * (same argument meaning, same result block layout; src/probability.py:173-186, 232-253), so a training step needs
+     * no separate finalisation launch.  obj_fin_result NULL: not requested. */
+    float* obj_fin_result;          /* [DUN_RES_FLOATS(depth+1)] */
+    double* obj_fin_sums;           /* [depth+1] per-depth sums (nullable) */
+    const float* obj_fin_q_logits;  /* [depth+1] (DUN_OBJ_VI) or NULL (DUN_OBJ_MLL) */
+    const float* obj_fin_logprior;  /* [depth+1] */
+    const float* obj_fin_prior_ll;  /* [depth+1] or NULL */
+    double obj_fin_N_train, obj_fin_batch, obj_fin_beta, obj_fin_eps;
+    int obj_fin_objective;          /* DUN_OBJ_VI / DUN_OBJ_MLL */
 } dun_fc_ctx;
 
 size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L);
@@ -249,12 +276,32 @@ int dun_fc_obj_num_partials(int B, int O);
  * BatchNorm apply, residual add, head row-dot and the likelihood terms in ONE pass over the [B,W] plane, so a caller of
  * the staged entries needs dun_fc_head_depth for depth 0 only. */
 int dun_fc_head_is_fused(const dun_fc_ctx* c);
+/* 1 when a train-mode dun_fc_forward(c) with obj_w accumulates the head's weight / bias gradient partials into
+ * obj_dwpart / obj_dbpart (where dun_fc_head_is_fused, and on the one-launch small-net forward, which leaves ONE partial
+ * per row-owning workgroup, [dun_fc_obj_num_partials][W], in the first rows of obj_dwpart): a caller allocates the two
+ * buffers only then. */
+int dun_fc_head_grads_in_forward(const dun_fc_ctx* c);
 
 /* Whole net in one call.  W <= 128 (W % 4 == 0) with B <= 2048 -- the toy / UCI nets of experiments/toy/train_toy.py
- * and experiments/regression -- run one column-owned launch per block (smallnet.hip) instead of the tiled GEMM
- * sequence; DUN_SMALLNET=0 in the environment selects the tiled path.  Results agree to fp32 rounding. */
+ * and experiments/regression -- do not run the tiled GEMM sequence:
+ *   mode 2 (default; needs c->sync, one output, L <= 255): ONE launch for the whole forward and ONE for the whole
+ *          backward (persist.hip): a workgroup owns 16 rows of the batch through every block, hidden state in LDS,
+ *          Linear layers on f32 MFMA tiles; the only data that crosses workgroups are BatchNorm's per-column partial
+ *          statistics, exchanged once per block as tagged 16-byte records -- no grid barrier, no kernel boundary;
+ *   mode 1: one column-owned launch per block (smallnet.hip);
+ *   mode 0: the tiled path.
+ * dun_fc_small_net_mode(m) selects the mode for later calls and returns the previous one (m < 0: query only); the
+ * environment sets the initial mode: DUN_SMALLNET=0 -> 0, DUN_SMALLNET_PERSIST=0 -> 1.  Results of the three agree to
+ * fp32 rounding.  No counterpart in the reference (launch structure only). */
 int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream);  /* whole net, BatchNorm over the local batch */
 int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream); /* whole net, needs a train-mode forward */
+int dun_fc_small_net_mode(int mode);
+size_t dun_fc_sync_bytes(int B, int W); /* size of dun_fc_ctx.sync for this shape (0: shape never takes mode 2) */
+/* 1 when dun_fc_forward(c) will also finish the objective (obj_fin_* set and the forward is one launch). */
+int dun_fc_objective_in_forward(const dun_fc_ctx* c);
+/* Error word of the one-launch kernels, read back from c->sync (HOST call, synchronises the stream): 0, or the code of
+ * the exchange that gave up waiting for another workgroup (bounded spins; the outputs of such a call are NaN). */
+int dun_fc_sync_status(const dun_fc_ctx* c, dun_stream_t stream);
 
 /* The same work cut at the points where a batch-sharded job exchanges BatchNorm statistics:
  * forward:  input_layer; for i: block_linear(i) -> [all-reduce bn_sums] -> block_norm(i, global_batch); head
@@ -301,6 +348,17 @@ int dun_head_backward(const float* H, const float* w, const float* dact, int row
  * ---------------------------------------------------------------------------------------------------- */
 int dun_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
                  dun_stream_t stream);
+/* The same update for up to DUN_SGD_MAX_SEGMENTS tensors in ONE launch (flat trunk parameters + q_logits + log_std of a
+ * small net; the conv parameters of an image DUN in a few launches instead of one per tensor). */
+#define DUN_SGD_MAX_SEGMENTS 24
+typedef struct dun_sgd_segment {
+    float* p;
+    const float* g;
+    float* buf;
+    size_t n;
+} dun_sgd_segment;
+int dun_sgd_step_multi(const dun_sgd_segment* segments /* host array */, int nseg, float lr, float momentum,
+                       float weight_decay, dun_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -194,6 +194,7 @@ class CpuBackend(object):
         m, p = buf.model, buf.model.stacked
         z = buf.Z[i if buf.train else 0]
         if buf.train:
+            m.num_batches_tracked[i] += 1  # (the kernels that update the running statistics do this: dun_fc_ctx.num_batches_tracked)
             mean = buf.bn_sums[0] / global_batch
             var = (buf.bn_sums[1] / global_batch - mean ** 2).clamp(min=0)
             buf.bn_mean[i] = mean.float()
