@@ -141,6 +141,14 @@ __device__ __forceinline__ float wave_allmax(float v) {
     return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
+__device__ __forceinline__ double wave_allmax(double v) {
+    v = fmax(v, dpp_move<DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_move<DPP_QUAD_XOR2>(v));
+    v = fmax(v, dpp_move<DPP_ROW_HALF_MIRROR>(v));
+    v = fmax(v, dpp_move<DPP_ROW_MIRROR>(v));
+    return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
+}
+
 constexpr float LOG_SQRT_2PI_F = 0.91893853320467274178f;
 constexpr double LOG_SQRT_2PI_D = 0.91893853320467274178;
 

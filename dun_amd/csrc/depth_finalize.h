@@ -7,7 +7,9 @@
 
 namespace dun {
 
-// One wavefront turns the per-depth sums into everything the objective and its backward need (fp64 inside).
+// One wavefront (all 64 lanes active) turns the per-depth sums into everything the objective and its backward need (fp64
+// inside).  Its dozen wave-wide reductions run on the DPP path: as ds_bpermute butterflies over doubles they were most
+// of the 7 us this took for D = 11.
 // `sums` may live in global memory or in LDS (generic pointer).
 __device__ __forceinline__ void depth_finalize_body(const double* sums, int gaussian,
                                                     const float* __restrict__ q_logits,
@@ -40,14 +42,14 @@ __device__ __forceinline__ void depth_finalize_body(const double* sums, int gaus
         joint_o[d] = (float)J;
         mx = fmax(mx, J + (double)logprior[d]);
     }
-    mx = wave_max(mx);
+    mx = wave_allmax(mx);
     double se = 0.0;
     for (int d = lane; d < D; d += 64) {
         const double LL = gaussian ? -batch * (LOG_SQRT_2PI_D + log(sigma)) - 0.5 * sums[d] * inv_var : sums[d];
         const double J = (N / batch) * LL + (prior_ll ? (double)prior_ll[d] : 0.0);
         se += exp(J + (double)logprior[d] - mx);
     }
-    se = wave_sum(se);
+    se = wave_allsum(se);
     const double log_marg = mx + log(se);
 
     // q = softmax(q_logits) and log q = log_softmax(q_logits) in fp32, exactly the arithmetic the reference's
@@ -55,9 +57,9 @@ __device__ __forceinline__ void depth_finalize_body(const double* sums, int gaus
     float qmx = -INFINITY, qs = 0.f;
     if (objective == DUN_OBJ_VI) {
         for (int d = lane; d < D; d += 64) qmx = fmaxf(qmx, q_logits[d]);
-        qmx = wave_max(qmx);
+        qmx = wave_allmax(qmx);
         for (int d = lane; d < D; d += 64) qs += expf(q_logits[d] - qmx);
-        qs = wave_sum(qs);
+        qs = wave_allsum(qs);
     }
     const float log_qs = logf(qs);
 
@@ -83,11 +85,11 @@ __device__ __forceinline__ void depth_finalize_body(const double* sums, int gaus
         w_o[d] = (float)wgt;
         if (gaussian) dls += wgt * (sums[d] * inv_var - batch);
     }
-    E = wave_sum(E);
-    KL = wave_sum(KL);
-    Asum = wave_sum(Asum);
-    Csum = wave_sum(Csum);
-    dls = wave_sum(dls);
+    E = wave_allsum(E);
+    KL = wave_allsum(KL);
+    Asum = wave_allsum(Asum);
+    Csum = wave_allsum(Csum);
+    dls = wave_allsum(dls);
 
     for (int d = lane; d < D; d += 64) {
         double dq = 0.0;

@@ -34,10 +34,24 @@ constexpr int PN_MAX_P = 128;
 constexpr int PN_MAX_W = 128;
 constexpr int PN_MAX_L = 255;
 constexpr int PN_HDR_BYTES = 256;    // sync header: word 0 epoch, word 1 error code, word 2 finalisation ticket
+constexpr int PN_STAGE_DIN = 32;     // input widths up to this are staged in LDS for the input layer
 constexpr int PN_REC_STRIDE = 128;   // records per (parity, workgroup) row, one per column
 constexpr long long PN_TIMEOUT_TICKS = 200000000LL;  // wall_clock64 runs at 100 MHz: 2 s
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// -DPN_PROFILE (scripts/dev/pn_phases.py): wave 0 of every workgroup stamps the 100 MHz wall clock into the unused record
+// columns 104..127 of its two record rows (48 stamps per row)
+#ifdef PN_PROFILE
+#define PN_STAMP(k)                                                                                                 \
+    do {                                                                                                            \
+        if (threadIdx.x == 0 && (k) < 96)                                                                           \
+            reinterpret_cast<long long*>(reinterpret_cast<char*>(p.sync) +                                          \
+                                         pn_rec_offset((k) / 48, p.P, blockIdx.x, 104))[(k) % 48] = wall_clock64(); \
+    } while (0)
+#else
+#define PN_STAMP(k) do { } while (0)
+#endif
 
 static int g_small_net_mode = -1;  // -1: take it from the environment on first use
 
@@ -92,29 +106,50 @@ __device__ __forceinline__ void pn_gather(const PnXch& x, int parity, int col, b
     const int M = (x.P + 3) >> 2;
     double s1 = 0.0, s2 = 0.0;
     for (int m0 = 0; m0 < M; m0 += CH) {
+        // A full sweep first (all records of this chunk in flight together); if some are not tagged yet, WATCH the first
+        // missing one with a single load per lane until it arrives, then sweep again: the chip's 200-odd polling waves
+        // would otherwise re-read every record every round (MB per round through the fabric the records travel on).
         u32x4 g[CH];
         const long long t_begin = wall_clock64();
         for (;;) {
             // (compiler barrier: the records change under this loop; it keeps the loads inside it and, with every
             // access to them being an sc1 buffer access, nothing of them is cached in registers or L1)
             asm volatile("" ::: "memory");
-            bool ok = true;
+            unsigned missing = 0;  // wave-uniform: chunk entries some lane still waits for
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int pi = q + 4 * (m0 + u);
                 g[u] = __builtin_amdgcn_raw_buffer_load_b128(x.rs, pn_rec_offset(parity, x.P, min(pi, x.P - 1), col), 0, 16);
-                ok = ok && (!(active && pi < x.P) || (g[u][1] == tag && g[u][3] == tag));
             }
-            if (__all(ok)) break;
-            if (*reinterpret_cast<volatile int*>(x.abort_flag)) break;  // this launch is already lost: drain
-            if (wall_clock64() - t_begin > PN_TIMEOUT_TICKS) {
-                if (lane == 0) {
-                    *reinterpret_cast<volatile int*>(x.abort_flag) = 1;
-                    __hip_atomic_store(x.words + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int pi = q + 4 * (m0 + u);
+                const bool ok = !(active && pi < x.P) || (g[u][1] == tag && g[u][3] == tag);
+                if (!__all(ok)) missing |= 1u << u;
+            }
+            if (missing == 0) break;
+            const int pw = q + 4 * (m0 + __builtin_ctz(missing));
+            const int woff = pn_rec_offset(parity, x.P, min(pw, x.P - 1), col);
+            bool lost = false;
+            for (;;) {
+                asm volatile("" ::: "memory");
+                const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(x.rs, woff, 0, 16);
+                const bool ok = !(active && pw < x.P) || (r[1] == tag && r[3] == tag);
+                if (__all(ok)) break;
+                if (*reinterpret_cast<volatile int*>(x.abort_flag)) {  // this launch is already lost: drain
+                    lost = true;
+                    break;
                 }
-                break;
+                if (wall_clock64() - t_begin > PN_TIMEOUT_TICKS) {
+                    if (lane == 0) {
+                        *reinterpret_cast<volatile int*>(x.abort_flag) = 1;
+                        __hip_atomic_store(x.words + 1, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    lost = true;
+                    break;
+                }
             }
-            __builtin_amdgcn_s_sleep(2);
+            if (lost) break;
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -135,9 +170,11 @@ __device__ __forceinline__ void pn_gather(const PnXch& x, int parity, int col, b
             }
         }
     }
-    const int j = lane & 15;
-    t1 = (__shfl(s1, j, 64) + __shfl(s1, j + 16, 64)) + (__shfl(s1, j + 32, 64) + __shfl(s1, j + 48, 64));
-    t2 = (__shfl(s2, j, 64) + __shfl(s2, j + 16, 64)) + (__shfl(s2, j + 32, 64) + __shfl(s2, j + 48, 64));
+    // (q0 + q1) + (q2 + q3) by two butterfly steps: addition commutes, so all four lane groups end with the same bits
+    s1 += __shfl_xor(s1, 16, 64);
+    s2 += __shfl_xor(s2, 16, 64);
+    t1 = s1 + __shfl_xor(s1, 32, 64);
+    t2 = s2 + __shfl_xor(s2, 32, 64);
 }
 
 // sum over the four lane groups of a wave (rows 4q .. 4q+3 of a column live in lane group q of the MFMA result layout)
@@ -215,6 +252,8 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
     __shared__ float s_coef[PN_MAX_L + 1];
     __shared__ float s_gb[PN_R];
     __shared__ double s_sums[PN_MAX_L + 1];
+    __shared__ float s_x[PN_R][PN_STAGE_DIN];
+    __shared__ float s_win[PN_MAX_W][PN_STAGE_DIN + 1];
     __shared__ int s_abort, s_ticket;
 
     const int t = threadIdx.x, lane = t & 63;
@@ -223,6 +262,7 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
     const int B = p.B, W = p.W, depth = p.depth, D = depth + 1;
     const int nvalid = min(PN_R, B - r0);
     const bool exchanging = TRAIN && depth > 0;
+    PN_STAMP(90);
 
     PnXch xch;
     xch.rs = __builtin_amdgcn_make_buffer_rsrc(p.sync, 0, p.sync_bytes, 0x00020000);
@@ -234,9 +274,52 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
     if (exchanging) base = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == 0) s_abort = 0;
 
+    // this wave's slice of a block's weights: wq[s][e] = W_i[n][16 s + 4 (lane >> 4) + e], n = 16 wv + (lane & 15)
+    const int col = 16 * wv + (lane & 15), q = lane >> 4;
+    const bool colok = wv < NT && col < W;
+    auto load_w = [&](int i, f32x4 (&dst)[NT]) {
+        const float* wi = p.w + (size_t)i * W * W + (size_t)min(col, W - 1) * W;
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            const int k = 16 * s + 4 * q;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wi + min(k, W - 4));
+            dst[s] = (colok && k < W) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // per-column parameters of a block (this lane's column), fetched one block ahead like the weights
+    struct ColP { float bias, gm, bt, rmean, rvar; };
+    auto load_colp = [&](int i, ColP& c) {
+        const size_t pi = (size_t)i * W + min(col, W - 1);
+        c.bias = p.b[pi]; c.gm = p.gamma[pi]; c.bt = p.beta[pi];
+        c.rmean = 0.f; c.rvar = 1.f;
+        if (!TRAIN || pid == 0) { c.rmean = p.running_mean[pi]; c.rvar = p.running_var[pi]; }
+    };
+    // two register sets, used alternately by even and odd blocks (a copy between them would wait for the prefetch)
+    f32x4 wA[NT], wB[NT];
+    ColP cA = {0.f, 1.f, 0.f, 0.f, 1.f}, cB = cA;
+    if (depth > 0 && wv < NT) {  // the longest latency of the prologue goes out first
+        load_w(0, wA);
+        load_colp(0, cA);
+    }
+
+    // ---- input layer (no activation) ---------------------------------------------------------------------------------
+    // din <= 32: x rows and w_in staged in LDS by coalesced loads that are all in flight together; thread (c, rq) then
+    // takes rows 4rq .. 4rq+3 of column c.  Wider inputs read both operands from global memory inside the k loop.
+    const bool staged = p.din <= PN_STAGE_DIN;
+    if (staged) {
+        for (int idx = t; idx < PN_R * p.din; idx += PN_T) {
+            const int r = idx / p.din, k = idx - r * p.din;
+            s_x[r][k] = p.x[(size_t)min(r0 + r, B - 1) * p.din + k];
+        }
+        for (int idx = t; idx < W * p.din; idx += PN_T) {
+            const int c = idx / p.din, k = idx - c * p.din;
+            s_win[c][k] = p.w_in[idx];
+        }
+    }
+
     // per-depth coefficient of the likelihood gradient: d(-objective/N)/d act = coef_d * (y - act)
     const bool has_obj = p.y != nullptr;
-    if (has_obj && wv == 0) {
+    if (has_obj && wv == PN_T / 64 - 1) {
         const float sigma = fmaxf(expf(p.log_std[0]), 1e-4f);
         const float scale = -p.inv_batch / (sigma * sigma);
         float mx = 0.f, ssum = 1.f;
@@ -255,19 +338,39 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
         }
     }
 
-    // ---- input layer (no activation): thread (c, rq) takes rows 4rq .. 4rq+3 of column c ------------------------------
+    // head: thread (row = t >> 5, part = t & 31) holds four columns of its row
+    const int hrow = t >> 5, hpart = t & 31;
+    f32x4 wo4 = {0.f, 0.f, 0.f, 0.f};
+    if (hpart * 4 < W) wo4 = *reinterpret_cast<const f32x4*>(p.w_out + hpart * 4);  // (W % 4 == 0; w_out 16-byte aligned: host)
+    const float b0 = p.b_out[0];
+    const float yv = has_obj ? p.y[min(r0 + hrow, B - 1)] : 0.f;
+    const bool want_dw = p.dwpart != nullptr;
+    f32x4 gw = {0.f, 0.f, 0.f, 0.f};
+    float gb = 0.f;
+
+    PN_STAMP(91);
+    if (staged) __syncthreads();  // s_x, s_win
     {
         const int c = t & 127, rq = t >> 7;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (c < W) {
-            const float* wr = p.w_in + (size_t)c * p.din;
-            const float* xr[4];
+            if (staged) {
+                for (int k = 0; k < p.din; ++k) {
+                    const float wk = s_win[c][k];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xr[j] = p.x + (size_t)min(r0 + 4 * rq + j, B - 1) * p.din;
-            for (int k = 0; k < p.din; ++k) {
-                const float wk = wr[k];
+                    for (int j = 0; j < 4; ++j) a[j] = fmaf(s_x[4 * rq + j][k], wk, a[j]);
+                }
+            } else {
+                const float* wr = p.w_in + (size_t)c * p.din;
+                const float* xr[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = fmaf(xr[j][k], wk, a[j]);
+                for (int j = 0; j < 4; ++j) xr[j] = p.x + (size_t)min(r0 + 4 * rq + j, B - 1) * p.din;
+#pragma unroll 4
+                for (int k = 0; k < p.din; ++k) {
+                    const float wk = wr[k];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = fmaf(xr[j][k], wk, a[j]);
+                }
             }
             const float bi = p.b_in[c];
 #pragma unroll
@@ -283,16 +386,6 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
             }
         }
     }
-
-    // head: thread (row = t >> 5, part = t & 31) holds four columns of its row
-    const int hrow = t >> 5, hpart = t & 31;
-    f32x4 wo4 = {0.f, 0.f, 0.f, 0.f};
-    if (hpart * 4 < W) wo4 = *reinterpret_cast<const f32x4*>(p.w_out + hpart * 4);  // (W % 4 == 0; w_out 16-byte aligned: host)
-    const float b0 = p.b_out[0];
-    const float yv = has_obj ? p.y[min(r0 + hrow, B - 1)] : 0.f;
-    const bool want_dw = p.dwpart != nullptr;
-    f32x4 gw = {0.f, 0.f, 0.f, 0.f};
-    float gb = 0.f;
 
     auto head = [&](int d, const float (*hb)[LD]) {
         f32x4 hv = {0.f, 0.f, 0.f, 0.f};
@@ -321,47 +414,28 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
         }
     };
 
-    // this wave's slice of a block's weights: wq[s][e] = W_i[n][16 s + 4 (lane >> 4) + e], n = 16 wv + (lane & 15)
-    const int col = 16 * wv + (lane & 15), q = lane >> 4;
-    const bool colok = wv < NT && col < W;
-    auto load_w = [&](int i, f32x4 (&dst)[NT]) {
-        const float* wi = p.w + (size_t)i * W * W + (size_t)min(col, W - 1) * W;
-#pragma unroll
-        for (int s = 0; s < NT; ++s) {
-            const int k = 16 * s + 4 * q;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(wi + min(k, W - 4));
-            dst[s] = (colok && k < W) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    f32x4 wq[NT], wnext[NT];
-    if (depth > 0 && wv < NT) load_w(0, wq);
-
+    PN_STAMP(0);
     __syncthreads();  // h_0 tile, s_coef, s_abort
-    head(0, hT[0]);
+    PN_STAMP(1);
 
-    for (int i = 0; i < depth; ++i) {
+    // Block i: matmul -> statistics -> publish -> [head of depth i on the tile just consumed: it runs while the records
+    // travel] -> gather -> [operands of block i+1 requested] -> normalise into the other tile -> barrier.
+    auto block = [&](int i, f32x4 (&wq)[NT], ColP& cp, f32x4 (&wnext)[NT], ColP& cpn) {
         const float (*hc)[LD] = hT[i & 1];
         float(*hn)[LD] = hT[(i + 1) & 1];
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        const unsigned tag = base + 1u + (unsigned)i;
         if (wv < NT) {
-            const size_t pi = (size_t)i * W + min(col, W - 1);
-            const float bias = p.b[pi], gm = p.gamma[pi], bt = p.beta[pi];
-            float rmean = 0.f, rvar = 1.f;
-            if (!TRAIN || pid == 0) {
-                rmean = p.running_mean[pi];
-                rvar = p.running_var[pi];
-            }
+            PN_STAMP(2 + 6 * i);
             const f32x4 acc = pn_tile_matmul<NT>(&hc[0][0], LD, wq);
-            if (i + 1 < depth) load_w(i + 1, wnext);  // in flight under the exchange
-            float z[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) z[j] = fmaxf(acc[j] + bias, 0.f);
-            float mu, rs;
+            for (int j = 0; j < 4; ++j) z[j] = fmaxf(acc[j] + cp.bias, 0.f);
             if (TRAIN) {
                 // Welford partial of this workgroup's rows: mean, then M2 around it (two passes over four registers)
-                float s = 0.f;
+                float sm = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s += (4 * q + j < nvalid) ? z[j] : 0.f;
-                const float mean_p = pn_sum_groups(s) / (float)nvalid;
+                for (int j = 0; j < 4; ++j) sm += (4 * q + j < nvalid) ? z[j] : 0.f;
+                const float mean_p = pn_sum_groups(sm) / (float)nvalid;
                 float m2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -369,48 +443,69 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
                     m2 += (4 * q + j < nvalid) ? dlt * dlt : 0.f;
                 }
                 m2 = pn_sum_groups(m2);
-                const unsigned tag = base + 1u + (unsigned)i;
+                PN_STAMP(3 + 6 * i);
                 if (q == 0 && colok) pn_publish(xch, i & 1, col, mean_p, m2, tag);
+            }
+        }
+        head(i, hc);
+        if (wv < NT) {
+            float mu, rs;
+            if (TRAIN) {
+                double t1, t2;
+                PN_STAMP(4 + 6 * i);
+                pn_gather<true>(xch, i & 1, min(col, W - 1), colok, tag, B, 0x100u + (unsigned)i, t1, t2);
+                PN_STAMP(5 + 6 * i);
+                if (i + 1 < depth) {  // behind the gather: its loads are not queued behind these
+                    load_w(i + 1, wnext);
+                    load_colp(i + 1, cpn);
+                }
+                const double inv_n = 1.0 / (double)B;
+                const double mean = t1 * inv_n;
+                double var = t2 * inv_n - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                mu = (float)mean;
+                rs = (float)rsqrt(var + (double)p.eps);
                 if (colok) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (4 * q + j < nvalid) p.Z[((size_t)i * B + r0 + 4 * q + j) * W + col] = z[j];
                 }
-                double t1, t2;
-                pn_gather<true>(xch, i & 1, min(col, W - 1), colok, tag, B, 0x100u + (unsigned)i, t1, t2);
-                const double n = (double)B;
-                const double mean = t1 / n;
-                double var = t2 / n - mean * mean;
-                var = var > 0.0 ? var : 0.0;
-                const double rstd = 1.0 / sqrt(var + (double)p.eps);
-                mu = (float)mean;
-                rs = (float)rstd;
                 if (pid == 0 && q == 0 && colok) {
-                    const double mom = (double)p.momentum;
+                    const size_t pi = (size_t)i * W + col;
+                    const double mom = (double)p.momentum, n = (double)B;
                     p.bn_mean[pi] = mu;
                     p.bn_rstd[pi] = rs;
-                    p.running_mean[pi] = (float)((1.0 - mom) * (double)rmean + mom * mean);
-                    p.running_var[pi] = (float)((1.0 - mom) * (double)rvar + mom * (var * (n / (n - 1.0))));
+                    p.running_mean[pi] = (float)((1.0 - mom) * (double)cp.rmean + mom * mean);
+                    p.running_var[pi] = (float)((1.0 - mom) * (double)cp.rvar + mom * (var * (n / (n - 1.0))));
                 }
             } else {
-                mu = rmean;
-                rs = 1.f / sqrtf(rvar + p.eps);
+                if (i + 1 < depth) {
+                    load_w(i + 1, wnext);
+                    load_colp(i + 1, cpn);
+                }
+                mu = cp.rmean;
+                rs = 1.f / sqrtf(cp.rvar + p.eps);
             }
-            const float sc = gm * rs;
+            const float sc = cp.gm * rs;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = 4 * q + j;
-                float o = (z[j] - mu) * sc + bt;
+                float o = (z[j] - mu) * sc + cp.bt;
                 if (p.residual) o = hc[row][col] + o;
                 hn[row][col] = colok ? o : 0.f;
                 if (colok && row < nvalid) p.H[((size_t)(i + 1) * B + r0 + row) * W + col] = o;
             }
-#pragma unroll
-            for (int s = 0; s < NT; ++s) wq[s] = wnext[s];
+            PN_STAMP(6 + 6 * i);
         }
-        __syncthreads();  // h_{i+1} tile complete; every wave is done with the A operand of block i
-        head(i + 1, hn);
+        __syncthreads();  // h_{i+1} tile complete; every wave is done with the A operand (and the head) of block i
+        PN_STAMP(7 + 6 * i);
+    };
+    for (int i = 0; i < depth; i += 2) {
+        block(i, wA, cA, wB, cB);
+        if (i + 1 < depth) block(i + 1, wB, cB, wA, cA);
     }
+    head(depth, hT[depth & 1]);
+    PN_STAMP(92);
 
     // ---- what the workgroup leaves behind -------------------------------------------------------------------------------
     if (want_dw) {
@@ -446,6 +541,7 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
             if (r < nvalid) p.act[(size_t)d * B + r0 + r] = nanv;
         }
     }
+    PN_STAMP(93);
     if (has_obj && p.partials != nullptr) {
         const bool fin = p.fin_result != nullptr;
         unsigned long long* pw = reinterpret_cast<unsigned long long*>(p.partials);
@@ -488,6 +584,7 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
             }
         }
     }
+    PN_STAMP(94);
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
@@ -555,30 +652,40 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
         for (int j = 0; j < 4; ++j) z[j] = p.Z[((size_t)i * B + min(r0 + 4 * q + j, B - 1)) * W + colc];
     };
 
+    // operands of a block: BatchNorm statistics and scale of this lane's column, its rows of ReLU(Linear) and of
+    // d loss / d act, this wave's slice of the weights.  Two register sets, used alternately by successive blocks.
+    struct Ops {
+        float mu, rs, gm;
+        float z[4], da[4];
+        f32x4 wq[NT];
+    };
+    auto load_ops = [&](int i, Ops& o) {
+        const size_t pi = (size_t)i * W + colc;
+        o.mu = p.bn_mean[pi]; o.rs = p.bn_rstd[pi]; o.gm = p.gamma[pi];
+        load_z(i, o.z);
+        dact_rows(i, o.da);
+        load_w(i, o.wq);
+    };
     float g[4] = {0.f, 0.f, 0.f, 0.f};
+    Ops oA, oB;
     if (wv < NT) {
+        if (L > 0) load_ops(L - 1, oA);  // the long latencies first
         float da[4];
         dact_rows(L, da);
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] = da[j] * wo;
     }
-    f32x4 wq[NT];
-    float z[4] = {0.f, 0.f, 0.f, 0.f}, zn[4];
-    if (L > 0 && wv < NT) {
-        load_z(L - 1, z);
-        load_w(L - 1, wq);
-    }
 
-    for (int i = L - 1; i >= 0; --i) {
+    // Block i: column sums of g and g*xhat -> publish -> gather -> [operands of block i-1 requested] -> dU into LDS and
+    // global memory -> barrier -> g = [g +] dU W_i + dact_i w_out on the matrix cores.
+    auto block = [&](int i, Ops& o, Ops& on) {
         const int phase = L - 1 - i;
         float(*dt)[LD] = duT[phase & 1];
         if (wv < NT) {
-            const size_t pi = (size_t)i * W + colc;
-            const float mu = p.bn_mean[pi], rs = p.bn_rstd[pi], gm = p.gamma[pi];
             float xh[4], sg = 0.f, sgx = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                xh[j] = (z[j] - mu) * rs;
+                xh[j] = (o.z[j] - o.mu) * o.rs;
                 sg += g[j];            // (rows past the batch carry g = 0)
                 sgx += g[j] * xh[j];
             }
@@ -586,38 +693,37 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
             sgx = pn_sum_groups(sgx);
             const unsigned tag = base + 1u + (unsigned)phase;
             if (q == 0 && colok) pn_publish(xch, phase & 1, col, sg, sgx, tag);
-            if (i > 0) load_z(i - 1, zn);  // the next block's operands travel under the exchange
             double t1, t2;
             pn_gather<false>(xch, phase & 1, colc, colok, tag, B, 0x200u + (unsigned)phase, t1, t2);
+            if (i > 0) load_ops(i - 1, on);  // behind the gather: its loads are not queued behind these
             const double inv_n = 1.0 / (double)B;
             const float mg = (float)(t1 * inv_n), mgx = (float)(t2 * inv_n);
             if (pid == 0 && q == 0 && colok) {
-                p.dbeta[pi] = (float)t1;
-                p.dgamma[pi] = (float)t2;
+                p.dbeta[(size_t)i * W + col] = (float)t1;
+                p.dgamma[(size_t)i * W + col] = (float)t2;
             }
-            const float k0 = gm * rs;
+            const float k0 = o.gm * o.rs;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = 4 * q + j;
                 const bool live = colok && row < nvalid;
-                const float du = (live && z[j] > 0.f) ? k0 * (g[j] - mg - xh[j] * mgx) : 0.f;
+                const float du = (live && o.z[j] > 0.f) ? k0 * (g[j] - mg - xh[j] * mgx) : 0.f;
                 dt[row][col] = du;
                 if (live) p.dU[((size_t)i * B + r0 + row) * W + col] = du;
             }
         }
-        __syncthreads();  // dU tile of this block complete (the other slot is still being read by no one: see below)
+        __syncthreads();  // dU tile of this block complete
         if (wv < NT) {
-            const f32x4 acc = pn_tile_matmul<NT>(&dt[0][0], LD, wq);
-            if (i > 0) load_w(i - 1, wq);
-            float da[4];
-            dact_rows(i, da);
+            const f32x4 acc = pn_tile_matmul<NT>(&dt[0][0], LD, o.wq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = (p.residual ? g[j] : 0.f) + acc[j] + da[j] * wo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) z[j] = zn[j];
+            for (int j = 0; j < 4; ++j) g[j] = (p.residual ? g[j] : 0.f) + acc[j] + o.da[j] * wo;
         }
         // (two dU slots: a wave writes slot (phase+1)&1 only after the barrier of phase, behind which every wave has finished
         // reading slot (phase-1)&1 = (phase+1)&1 in the matmul of phase-1)
+    };
+    for (int i = L - 1; i >= 0; i -= 2) {
+        block(i, oA, oB);
+        if (i > 0) block(i - 1, oB, oA);
     }
     if (colok) {
 #pragma unroll

@@ -570,16 +570,18 @@ __global__ __launch_bounds__(SN_T) void sn_dw_batched_kernel(SnDwP p) {
     float* obuf = reinterpret_cast<float*>(sn_smem + SN_OFF_OBUF);
     const int c0 = blockIdx.x * SN_NC, i = blockIdx.y;
     const size_t plane = (size_t)p.B * p.W;
-    if (i == p.L + 1) {  // fp64, fixed order
-        const int t = threadIdx.x;
-        if (t < SN_NC) {
+    if (i == p.L + 1) {  // fp64, fixed order: a wavefront per column, lanes stride over the partials
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (wv < SN_NC) {
             double a = 0.0;
-            for (int q = 0; q < p.P; ++q) a += (double)p.dwpart[(size_t)q * p.W + c0 + t];
-            p.dw_out[c0 + t] = (float)a;
-        } else if (t == 64 && blockIdx.x == 0) {
+            for (int q = lane; q < p.P; q += 64) a += (double)p.dwpart[(size_t)q * p.W + c0 + wv];
+            a = wave_sum(a);
+            if (lane == 0) p.dw_out[c0 + wv] = (float)a;
+        } else if (wv == SN_NC && blockIdx.x == 0) {
             double a = 0.0;
-            for (int q = 0; q < p.P; ++q) a += (double)p.dbpart[q];
-            p.db_out[0] = (float)a;
+            for (int q = lane; q < p.P; q += 64) a += (double)p.dbpart[q];
+            a = wave_sum(a);
+            if (lane == 0) p.db_out[0] = (float)a;
         }
         return;
     }
