@@ -386,13 +386,15 @@ def launch_ranks(args, argv):
     n = args.gpus
     port = _free_port()
     procs = []
+    import tempfile
+    out0 = tempfile.TemporaryFile()  # rank 0's stdout: a file, not a pipe (a pipe nobody drains blocks the writer at 64 KiB)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DUN_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # one JSON line comes from rank 0's stdout; what the other ranks might print there goes to our stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+                                      stdout=out0 if r == 0 else sys.stderr, stderr=sys.stderr))
     deadline = time.time() + args.launch_timeout
     failed = None
     live = set(range(n))
@@ -421,7 +423,8 @@ def launch_ranks(args, argv):
                 procs[r].kill()
         print("bench.py: rank %d of %d failed (%s); no result" % (failed[0], n, failed[1]), file=sys.stderr, flush=True)
         return 1
-    out = procs[0].stdout.read().decode()
+    out0.seek(0)
+    out = out0.read().decode()
     lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
     if len(lines) != 1:
         print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr, flush=True)

@@ -23,7 +23,7 @@ EXPORTS = [
     "dun_fc_block_norm", "dun_fc_block_apply", "dun_fc_head", "dun_fc_head_depth", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply", "dun_fc_bwd_block_dx", "dun_fc_bwd_block_dw",
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
     "dun_sgd_step_multi", "dun_predict_gauss_step", "dun_fc_small_net_mode", "dun_fc_sync_bytes", "dun_fc_sync_status",
-    "dun_fc_objective_in_forward", "dun_fc_head_grads_in_forward",
+    "dun_fc_objective_in_forward", "dun_fc_head_grads_in_forward", "dun_copy_pair",
 ]
 
 SGD_MAX_SEGMENTS = 24
@@ -68,7 +68,7 @@ class FcCtx(C.Structure):
                 ("obj_fin_result", C.c_void_p), ("obj_fin_sums", C.c_void_p), ("obj_fin_q_logits", C.c_void_p),
                 ("obj_fin_logprior", C.c_void_p), ("obj_fin_prior_ll", C.c_void_p),
                 ("obj_fin_N_train", C.c_double), ("obj_fin_batch", C.c_double), ("obj_fin_beta", C.c_double),
-                ("obj_fin_eps", C.c_double), ("obj_fin_objective", C.c_int)]
+                ("obj_fin_eps", C.c_double), ("obj_fin_objective", C.c_int), ("obj_fin_defer", C.c_int)]
 
 
 class SgdSegment(C.Structure):
@@ -127,6 +127,7 @@ def _declare(lib):
         "dun_fc_sync_status": (i, [C.POINTER(FcCtx), vp]),
         "dun_fc_objective_in_forward": (i, [C.POINTER(FcCtx)]),
         "dun_fc_head_grads_in_forward": (i, [C.POINTER(FcCtx)]),
+        "dun_copy_pair": (i, [vp, vp, sz, vp, vp, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -175,3 +176,14 @@ def f32(t):
     if t.dtype != torch.float32:
         raise RuntimeError("dun_amd kernels compute in float32 (got %s)" % t.dtype)
     return ptr(t)
+
+
+def out_ptr(t):
+    """Pointer of an OUTPUT tensor a kernel writes a few scalars to: device memory, or pinned host memory (mapped into
+    the device's address space at the same address: a captured step leaves its returned scalars there directly)."""
+    if t.is_cuda:
+        return ptr(t)
+    if not t.is_pinned() or not t.is_contiguous():
+        raise RuntimeError("dun_amd kernels write to GPU tensors or contiguous pinned host tensors")
+    return t.data_ptr()
+

@@ -152,6 +152,38 @@ def _load_momentum(opt, saved):
                 memory_format=torch.channels_last if p.dim() == 4 and not p.is_contiguous() else torch.contiguous_format)
 
 
+def _validate_shapes(net, st):
+    """Every shape the loader is about to copy, checked before the first byte is overwritten: a checkpoint of the right
+    parameter COUNT but another width / depth must leave the wrapper as it was."""
+    here = net.model.state_dict()
+    saved = st["model"]
+    missing = [k for k in here if k not in saved]
+    extra = [k for k in saved if k not in here]
+    if missing or extra:
+        raise ValueError("checkpoint model state does not match this model: missing %s, unexpected %s" % (missing[:3], extra[:3]))
+    for k, v in here.items():
+        if tuple(saved[k].shape) != tuple(v.shape):
+            raise ValueError("checkpoint tensor %s has shape %s, this model's has %s" % (k, tuple(saved[k].shape), tuple(v.shape)))
+    pm = net.prob_model
+    if "q_logits" in st["prob_model"] and tuple(st["prob_model"]["q_logits"].shape) != tuple(pm.q_logits.shape):
+        raise ValueError("checkpoint q_logits has shape %s, this prob_model's has %s"
+                         % (tuple(st["prob_model"]["q_logits"].shape), tuple(pm.q_logits.shape)))
+    if isinstance(net.f_neg_loglike, torch.nn.Module) and st["f_neg_loglike"]:
+        for k, v in net.f_neg_loglike.state_dict().items():
+            if k in st["f_neg_loglike"] and tuple(st["f_neg_loglike"][k].shape) != tuple(v.shape):
+                raise ValueError("checkpoint likelihood tensor %s has shape %s, expected %s"
+                                 % (k, tuple(st["f_neg_loglike"][k].shape), tuple(v.shape)))
+    params = [p for g in net.optimizer.param_groups for p in g["params"]]
+    for sg in st["optimizer"]["param_groups"]:
+        if sg.get("dampening", 0) != 0 or sg.get("nesterov", False):
+            raise ValueError("checkpoint optimizer uses dampening / nesterov, which the fused SGD step does not implement")
+    for idx, p in enumerate(params):
+        e = st["optimizer"]["state"].get(idx, st["optimizer"]["state"].get(str(idx)))
+        m = None if e is None else e.get("momentum_buffer")
+        if m is not None and tuple(m.shape) != tuple(p.shape):
+            raise ValueError("momentum of parameter %d has shape %s, expected %s" % (idx, tuple(m.shape), tuple(p.shape)))
+
+
 def load_state(net, filename_or_state, to_cpu=False):
     """Restore a constructed wrapper from ``save_state``'s file (or the dict itself).  -> epoch, or (epoch, best_err)
     like the reference's ``load`` (src/utils.py:158-182).  Nothing in the file is executed."""
@@ -168,6 +200,7 @@ def load_state(net, filename_or_state, to_cpu=False):
     n_here = sum(len(g["params"]) for g in net.optimizer.param_groups)
     if n_saved != n_here:
         raise ValueError("checkpoint optimizer covers %d parameters, this wrapper's has %d" % (n_saved, n_here))
+    _validate_shapes(net, st)
     net.model.load_state_dict(st["model"])
     with torch.no_grad():
         if "q_logits" in st["prob_model"]:

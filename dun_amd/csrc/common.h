@@ -175,7 +175,7 @@ __device__ __forceinline__ float depth_weight(const float* __restrict__ w, int w
 // `red` is caller-provided LDS of at least NT/64 elements; the call contains two barriers.
 template <int NT, typename T>
 __device__ __forceinline__ T block_sum(T v, T* red) {
-    v = wave_sum(v);
+    v = wave_allsum(v);  // (DPP path: every thread of the workgroup calls this, so all lanes are active)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wid] = v;

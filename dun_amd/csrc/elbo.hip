@@ -495,10 +495,26 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
                                                             const float* __restrict__ obj_src,
                                                             double* __restrict__ obj_dst) {
     __shared__ double red[4];
+    __shared__ float s_q[256];
     const int tid = threadIdx.x;
     const int idx = (blockIdx.x * 256 + tid) * 4;
     float mu[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
     const bool any = idx < n;
+    // what depends on nothing goes out first: at the sizes of a training step's metric pass (one workgroup, a few KB) the
+    // kernel is a chain of memory round trips, and every load issued late is one more of them
+    float yv[4] = {0.f, 0.f, 0.f, 0.f};
+    float ls = 0.f;
+    if (partials) {
+        ls = log_std[0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yv[e] = y[min(idx + e, n - 1)];
+    }
+    constexpr int DCH = 8;  // depths whose loads are in flight together
+    f32x4 first[DCH];
+    if (VEC && any) {
+#pragma unroll
+        for (int u = 0; u < DCH; ++u) first[u] = ld4_stream<NT>(act + (size_t)min(u, D - 1) * n + idx);
+    }
     // q given as logits (the post-step q(d) of DUN_VI.fit): softmax in fp32 as F.softmax, every wavefront for itself
     float qmx = 0.f, qinv = 1.f;
     if (q_is_logits) {
@@ -510,31 +526,44 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
         for (int i = lane; i < D; i += 64) s += expf(q[i] - qmx);
         qinv = wave_allsum(s);
     }
+    const bool q_in_lds = D <= 256;
+    if (q_in_lds) {
+        if (tid < D) s_q[tid] = q_is_logits ? expf(q[tid] - qmx) / qinv : q[tid];
+        __syncthreads();
+    }
     if (blockIdx.x == 0) {
         if (q_out)
-            for (int i = tid; i < D; i += 256) q_out[i] = q_is_logits ? expf(q[i] - qmx) / qinv : q[i];
+            for (int i = tid; i < D; i += 256) q_out[i] = q_in_lds ? s_q[i] : (q_is_logits ? expf(q[i] - qmx) / qinv : q[i]);
         if (obj_dst && tid == 0) obj_dst[0] = (double)obj_src[0];
     }
     if (any) {
-        for (int d = 0; d < D; ++d) {
-            const float qd = q_is_logits ? expf(q[d] - qmx) / qinv : q[d];
-            const float* a = act + (size_t)d * n + idx;
-            float v[4];
-            if (VEC) {
-                const f32x4 t = ld4_stream<NT>(a);
-                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-            } else {
+        for (int d0 = 0; d0 < D; d0 += DCH) {
+            f32x4 t[DCH];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (idx + e < n) ? a[e] : 0.f;
+            for (int u = 0; u < DCH; ++u) {
+                const float* a = act + (size_t)min(d0 + u, D - 1) * n + idx;
+                if (VEC) {
+                    t[u] = d0 == 0 ? first[u] : ld4_stream<NT>(a);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[u][e] = a[min(e, n - 1 - idx)] * ((idx + e < n) ? 1.f : 0.f);
+                }
             }
-            // every product rounded on its own, as (q * preds).sum(0) and (q * preds**2).sum(0) do in the
-            // reference: an FMA here would make var = sum(q a^2) - mu^2 come out slightly negative (-> NaN std)
-            // where the reference gets exactly 0 (one-hot posteriors, single depth)
-            // (hipcc contracts a*b+c into an FMA by default, through __fmul_rn too: rounded() hides each product)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                mu[e] += rounded(qd * v[e]);
-                m2[e] += rounded(qd * rounded(v[e] * v[e]));
+            for (int u = 0; u < DCH; ++u) {
+                const int d = d0 + u;
+                if (d < D) {
+                    const float qd = q_in_lds ? s_q[d] : (q_is_logits ? expf(q[d] - qmx) / qinv : q[d]);
+                    // every product rounded on its own, as (q * preds).sum(0) and (q * preds**2).sum(0) do in the
+                    // reference: an FMA here would make var = sum(q a^2) - mu^2 come out slightly negative (-> NaN std)
+                    // where the reference gets exactly 0 (one-hot posteriors, single depth)
+                    // (hipcc contracts a*b+c into an FMA by default, through __fmul_rn too: rounded() hides each product)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        mu[e] += rounded(qd * t[u][e]);
+                        m2[e] += rounded(qd * rounded(t[u][e] * t[u][e]));
+                    }
+                }
             }
         }
     }
@@ -551,12 +580,12 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
             }
         }
         if (partials) {
-            const float sig = fmaxf(expf(log_std[0]), 1e-4f);
+            const float sig = fmaxf(expf(ls), 1e-4f);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (idx + e < n) {
                     const float st = sqrtf(sig * sig + sd[e] * sd[e]);
-                    const float r = y[idx + e] - mu[e];
+                    const float r = yv[e] - mu[e];
                     nll += (double)(LOG_SQRT_2PI_F + logf(st) + r * r / (2.f * st * st));
                     se += (double)(r * r);
                 }

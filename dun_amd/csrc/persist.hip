@@ -177,6 +177,14 @@ __device__ __forceinline__ void pn_gather(const PnXch& x, int parity, int col, b
     t2 = s2 + __shfl_xor(s2, 32, 64);
 }
 
+// Workgroup barrier for data handed over through LDS only: waits for this wave's LDS operations, not for its global loads
+// and stores (__syncthreads() drains both, which would expose the latency of every prefetch and result store in flight)
+__device__ __forceinline__ void pn_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // sum over the four lane groups of a wave (rows 4q .. 4q+3 of a column live in lane group q of the MFMA result layout)
 __device__ __forceinline__ float pn_sum_groups(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -278,18 +286,22 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
     const int col = 16 * wv + (lane & 15), q = lane >> 4;
     const bool colok = wv < NT && col < W;
     auto load_w = [&](int i, f32x4 (&dst)[NT]) {
-        const float* wi = p.w + (size_t)i * W * W + (size_t)min(col, W - 1) * W;
+        // (32-bit offsets from the uniform base: with 64-bit per-lane addresses the compiler kept one address pair per
+        // load alive across the loop)
+        const unsigned wi = (unsigned)i * (unsigned)(W * W) + (unsigned)min(col, W - 1) * (unsigned)W;
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
             const int k = 16 * s + 4 * q;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(wi + min(k, W - 4));
-            dst[s] = (colok && k < W) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (times a 0/1 mask, not a select: the compiler sinks a load whose value is only selected into a branch of
+            // its own, and every such branch waits for its load alone -- one memory round trip after another)
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + (wi + (unsigned)min(k, W - 4)));
+            dst[s] = v * ((colok && k < W) ? 1.f : 0.f);
         }
     };
     // per-column parameters of a block (this lane's column), fetched one block ahead like the weights
     struct ColP { float bias, gm, bt, rmean, rvar; };
     auto load_colp = [&](int i, ColP& c) {
-        const size_t pi = (size_t)i * W + min(col, W - 1);
+        const unsigned pi = (unsigned)i * (unsigned)W + (unsigned)min(col, W - 1);
         c.bias = p.b[pi]; c.gm = p.gamma[pi]; c.bt = p.beta[pi];
         c.rmean = 0.f; c.rvar = 1.f;
         if (!TRAIN || pid == 0) { c.rmean = p.running_mean[pi]; c.rvar = p.running_var[pi]; }
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
     float gb = 0.f;
 
     PN_STAMP(91);
-    if (staged) __syncthreads();  // s_x, s_win
+    if (staged) pn_lds_barrier();  // s_x, s_win
     {
         const int c = t & 127, rq = t >> 7;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
     };
 
     PN_STAMP(0);
-    __syncthreads();  // h_0 tile, s_coef, s_abort
+    pn_lds_barrier();  // h_0 tile, s_coef, s_abort
     PN_STAMP(1);
 
     // Block i: matmul -> statistics -> publish -> [head of depth i on the tile just consumed: it runs while the records
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
             }
             PN_STAMP(6 + 6 * i);
         }
-        __syncthreads();  // h_{i+1} tile complete; every wave is done with the A operand (and the head) of block i
+        pn_lds_barrier();  // h_{i+1} tile complete; every wave is done with the A operand (and the head) of block i
         PN_STAMP(7 + 6 * i);
     };
     for (int i = 0; i < depth; i += 2) {
@@ -617,6 +629,7 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
     xch.abort_flag = &s_abort;
     xch.P = p.P;
     xch.pid = pid;
+    PN_STAMP(90);
     unsigned base = 0;
     if (L > 0) base = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == 0) s_abort = 0;
@@ -631,25 +644,26 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = r0 + 4 * q + j;
-            const float v = p.dact[(size_t)d * B + min(row, B - 1)];
-            da[j] = row < B ? v : 0.f;
+            const float v = p.dact[(unsigned)d * (unsigned)B + (unsigned)min(row, B - 1)];
+            da[j] = v * (row < B ? 1.f : 0.f);
         }
     };
     // operand of g = dU W_i: the contraction runs over W_i's OUTPUT index, wq[s][e] = W_i[16 s + 4 q + e][col]
     auto load_w = [&](int i, f32x4 (&dst)[NT]) {
-        const float* wi = p.w + (size_t)i * W * W + colc;
+        const unsigned wi = (unsigned)i * (unsigned)(W * W) + (unsigned)colc;  // (32-bit offsets: see the forward)
 #pragma unroll
         for (int s = 0; s < NT; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = 16 * s + 4 * q + e;
-                const float v = wi[(size_t)min(k, W - 1) * W];
-                dst[s][e] = (colok && k < W) ? v : 0.f;
+                const float v = p.w[wi + (unsigned)min(k, W - 1) * (unsigned)W];
+                dst[s][e] = v * ((colok && k < W) ? 1.f : 0.f);  // (mask, not select: see the forward's load_w)
             }
     };
     auto load_z = [&](int i, float (&z)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) z[j] = p.Z[((size_t)i * B + min(r0 + 4 * q + j, B - 1)) * W + colc];
+        for (int j = 0; j < 4; ++j)
+            z[j] = p.Z[((unsigned)i * (unsigned)B + (unsigned)min(r0 + 4 * q + j, B - 1)) * (unsigned)W + (unsigned)colc];
     };
 
     // operands of a block: BatchNorm statistics and scale of this lane's column, its rows of ReLU(Linear) and of
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
         f32x4 wq[NT];
     };
     auto load_ops = [&](int i, Ops& o) {
-        const size_t pi = (size_t)i * W + colc;
+        const unsigned pi = (unsigned)i * (unsigned)W + (unsigned)colc;
         o.mu = p.bn_mean[pi]; o.rs = p.bn_rstd[pi]; o.gm = p.gamma[pi];
         load_z(i, o.z);
         dact_rows(i, o.da);
@@ -681,6 +695,7 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
     auto block = [&](int i, Ops& o, Ops& on) {
         const int phase = L - 1 - i;
         float(*dt)[LD] = duT[phase & 1];
+        PN_STAMP(1 + 5 * phase);
         if (wv < NT) {
             float xh[4], sg = 0.f, sgx = 0.f;
 #pragma unroll
@@ -692,9 +707,11 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
             sg = pn_sum_groups(sg);
             sgx = pn_sum_groups(sgx);
             const unsigned tag = base + 1u + (unsigned)phase;
+            PN_STAMP(2 + 5 * phase);
             if (q == 0 && colok) pn_publish(xch, phase & 1, col, sg, sgx, tag);
             double t1, t2;
             pn_gather<false>(xch, phase & 1, colc, colok, tag, B, 0x200u + (unsigned)phase, t1, t2);
+            PN_STAMP(3 + 5 * phase);
             if (i > 0) load_ops(i - 1, on);  // behind the gather: its loads are not queued behind these
             const double inv_n = 1.0 / (double)B;
             const float mg = (float)(t1 * inv_n), mgx = (float)(t2 * inv_n);
@@ -712,7 +729,9 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
                 if (live) p.dU[((size_t)i * B + r0 + row) * W + col] = du;
             }
         }
-        __syncthreads();  // dU tile of this block complete
+        PN_STAMP(4 + 5 * phase);
+        pn_lds_barrier();  // dU tile of this block complete
+        PN_STAMP(5 + 5 * phase);
         if (wv < NT) {
             const f32x4 acc = pn_tile_matmul<NT>(&dt[0][0], LD, o.wq);
 #pragma unroll
@@ -732,6 +751,7 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
     }
     if (pid == 0 && t == 0 && L > 0)
         __hip_atomic_store(p.sync, base + (unsigned)L + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PN_STAMP(94);
     __syncthreads();
     if (s_abort && colok) {  // an exchange gave up: poison what the weight-gradient launch reads
 #pragma unroll
@@ -768,7 +788,7 @@ int pn_forward(const dun_fc_ctx* c, hipStream_t s) {
         p.partials = c->obj_partials;
         p.nparts = p.P;
         if (p.dact && c->obj_dwpart && c->obj_dbpart && c->train) { p.dwpart = c->obj_dwpart; p.dbpart = c->obj_dbpart; }
-        if (c->obj_fin_result) {
+        if (c->obj_fin_result && !c->obj_fin_defer) {
             DUN_REQUIRE(c->obj_fin_logprior != nullptr, "dun_fc_forward: obj_fin_result without obj_fin_logprior");
             DUN_REQUIRE(c->obj_fin_objective == DUN_OBJ_MLL || c->obj_fin_q_logits != nullptr,
                         "dun_fc_forward: the variational objective needs obj_fin_q_logits");

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "depth_finalize.h"
 
 namespace dun {
 
@@ -563,6 +564,13 @@ struct SnDwP {
     float* dw_out;
     float* db_out;
     int P;
+    // blockIdx.y == y_fin (>= 0: deferred finalisation of the objective, workgroup x == 0 only): dun_depth_finalize_partials
+    int y_fin, fin_D, fin_nparts, fin_objective;
+    const double* fin_partials;
+    double* fin_sums;
+    const float *fin_q_logits, *fin_logprior, *fin_prior_ll, *fin_log_std;
+    double fin_N, fin_batch, fin_beta, fin_eps;
+    float* fin_result;
 };
 __global__ __launch_bounds__(SN_T) void sn_dw_batched_kernel(SnDwP p) {
     extern __shared__ __attribute__((aligned(16))) char sn_smem[];
@@ -570,6 +578,26 @@ __global__ __launch_bounds__(SN_T) void sn_dw_batched_kernel(SnDwP p) {
     float* obuf = reinterpret_cast<float*>(sn_smem + SN_OFF_OBUF);
     const int c0 = blockIdx.x * SN_NC, i = blockIdx.y;
     const size_t plane = (size_t)p.B * p.W;
+    if (i == p.y_fin) {  // same arithmetic and summation order as depth_reduce_finalize_kernel (elbo.hip)
+        if (blockIdx.x != 0) return;
+        double* sh_sums = reinterpret_cast<double*>(sn_smem);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int d = wv; d < p.fin_D; d += SN_WAVES) {
+            double a = 0.0;
+            for (int k = lane; k < p.fin_nparts; k += 64) a += p.fin_partials[(size_t)d * p.fin_nparts + k];
+            a = wave_sum(a);
+            if (lane == 0) {
+                sh_sums[d] = a;
+                if (p.fin_sums) p.fin_sums[d] = a;
+            }
+        }
+        __syncthreads();
+        if (wv == 0)
+            depth_finalize_body(sh_sums, 1, p.fin_q_logits, p.fin_logprior, p.fin_prior_ll, p.fin_log_std, p.fin_D, p.fin_N,
+                                p.fin_batch, p.fin_beta, p.fin_eps, p.fin_objective, p.fin_result);
+        return;
+    }
+    if (i == p.L + 1 && p.dwpart == nullptr) return;
     if (i == p.L + 1) {  // fp64, fixed order: a wavefront per column, lanes stride over the partials
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         if (wv < SN_NC) {
@@ -741,7 +769,7 @@ int sn_backward_blocks(const dun_fc_ctx* c, float* dUall, hipStream_t s) {
     if (L > 0) {
         SnDwP q;
         memset(&q, 0, sizeof(q));
-        q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W; q.L = L;
+        q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W; q.L = L; q.y_fin = -1;
         const size_t lds = sn_lds(B);
         int rc = sn_allow_lds(sn_dw_batched_kernel, lds);
         if (rc) return rc;
@@ -760,14 +788,31 @@ int sn_dw_all(const dun_fc_ctx* c, const float* dUall, bool head_from_forward, h
     q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W; q.L = L;
     q.G = c->G; q.x = c->x; q.dw_in = c->g.w_in; q.db_in = c->g.b_in; q.din = c->din;
     q.vec_in = ((c->din & 3) == 0 && sn_al16(c->x) && sn_al16(c->g.w_in)) ? 1 : 0;
+    int ny = L + 1;
+    q.y_fin = -1;
     if (head_from_forward) {
         q.dwpart = c->obj_dwpart; q.dbpart = c->obj_dbpart; q.dw_out = c->g.w_out; q.db_out = c->g.b_out;
         q.P = (B + 15) / 16;
+        ny = L + 2;
+    }
+    if (c->obj_fin_result && c->obj_fin_defer && c->obj_y && c->obj_partials) {
+        // the forward left the partial sums and deferred the depth-level finalisation to this launch
+        DUN_REQUIRE(c->obj_fin_logprior != nullptr && (c->obj_fin_objective == DUN_OBJ_MLL || c->obj_fin_q_logits != nullptr),
+                    "dun_fc_backward: deferred finalisation without logprior / q_logits");
+        DUN_REQUIRE(c->depth + 1 <= 512, "dun_fc_backward: deferred finalisation of more than 512 depths");
+        q.y_fin = L + 2;  // (row L + 1 stays the head's, run or not: a workgroup of an unused row returns at once)
+        ny = L + 3;
+        q.fin_D = c->depth + 1; q.fin_nparts = (B + 15) / 16; q.fin_objective = c->obj_fin_objective;
+        q.fin_partials = c->obj_partials; q.fin_sums = c->obj_fin_sums;
+        q.fin_q_logits = c->obj_fin_q_logits; q.fin_logprior = c->obj_fin_logprior; q.fin_prior_ll = c->obj_fin_prior_ll;
+        q.fin_log_std = c->obj_log_std;
+        q.fin_N = c->obj_fin_N_train; q.fin_batch = c->obj_fin_batch; q.fin_beta = c->obj_fin_beta; q.fin_eps = c->obj_fin_eps;
+        q.fin_result = c->obj_fin_result;
     }
     const size_t lds = sn_lds(B);
     int rc = sn_allow_lds(sn_dw_batched_kernel, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(sn_dw_batched_kernel, dim3(W / SN_NC, L + (head_from_forward ? 2 : 1)), dim3(SN_T), lds, s, q);
+    hipLaunchKernelGGL(sn_dw_batched_kernel, dim3(W / SN_NC, ny), dim3(SN_T), lds, s, q);
     DUN_LAUNCH_CHECK();
     return DUN_OK;
 }

@@ -1357,3 +1357,37 @@ extern "C" int dun_sgd_step_multi(const dun_sgd_segment* segments, int nseg, flo
     DUN_LAUNCH_CHECK();
     return DUN_OK;
 }
+
+// ---- two device-to-device copies in one launch ---------------------------------------------------------------------
+namespace dun {
+__global__ __launch_bounds__(256) void copy_pair_kernel(char* d0, const char* s0, size_t n0, char* d1, const char* s1,
+                                                        size_t n1) {
+    char* d = blockIdx.y == 0 ? d0 : d1;
+    const char* s = blockIdx.y == 0 ? s0 : s1;
+    const size_t n = blockIdx.y == 0 ? n0 : n1;
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+        const size_t n16 = n / 16;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+            reinterpret_cast<f32x4*>(d)[i] = reinterpret_cast<const f32x4*>(s)[i];
+        for (size_t i = n16 * 16 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = s[i];
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = s[i];
+}
+}  // namespace dun
+
+extern "C" int dun_copy_pair(void* dst0, const void* src0, size_t bytes0, void* dst1, const void* src1, size_t bytes1,
+                             dun_stream_t stream) {
+    DUN_REQUIRE((bytes0 == 0 || (dst0 && src0)) && (bytes1 == 0 || (dst1 && src1)), "dun_copy_pair: null pointer");
+    const size_t nmax = bytes0 > bytes1 ? bytes0 : bytes1;
+    if (nmax == 0) return DUN_OK;
+    size_t blocks = (nmax / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_pair_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, STREAM, static_cast<char*>(dst0),
+                       static_cast<const char*>(src0), bytes0, static_cast<char*>(dst1), static_cast<const char*>(src1),
+                       bytes1);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}

@@ -89,6 +89,7 @@ class FcBuffers(object):
         c.obj_dwpart = c.obj_dbpart = None
         c.head_grads_from_forward = 0
         c.obj_fin_result = c.obj_fin_sums = c.obj_fin_q_logits = c.obj_fin_logprior = c.obj_fin_prior_ll = None
+        c.obj_fin_defer = 0
         if spec is None:
             c.obj_y = c.obj_w = c.obj_log_std = c.obj_dact = c.obj_partials = None
             self._obj = None
@@ -119,6 +120,9 @@ class FcBuffers(object):
             c.obj_fin_prior_ll = None
             c.obj_fin_N_train, c.obj_fin_batch = float(fin["N_train"]), float(fin["batch"])
             c.obj_fin_beta, c.obj_fin_eps, c.obj_fin_objective = float(fin["beta"]), float(fin["eps"]), int(fin["objective"])
+            # deferred: the backward of this context, which the caller runs next, finishes the objective in a spare
+            # workgroup of its weight-gradient launch (spec.res is valid once that backward has been enqueued)
+            c.obj_fin_defer = int(bool(fin.get("defer")) and self.train)
             if not L.lib().dun_fc_objective_in_forward(C.byref(c)):
                 c.obj_fin_result = c.obj_fin_sums = c.obj_fin_q_logits = c.obj_fin_logprior = None
                 spec.res = spec.sums = None
@@ -266,8 +270,8 @@ class HipBackend(object):
 
     def predict_step(self, act, q_logits, y, log_std, objective, out):
         """End of a regression training step in ONE launch: depth-marginal mean / std of `act` under q = softmax(q_logits)
-        (the post-step q(d)), the metric sums, q itself and the step's objective.  `out`: double [3] receiving
-        [objective, nll_sum, squared-error sum].  -> q (float [D]).  Falls back to None for batches that need the
+        (the post-step q(d)), the metric sums, q itself and the step's objective.  `out`: double [3] (device, or pinned
+        host memory) receiving [objective, nll_sum, squared-error sum].  -> q (float [D]).  Falls back to None for batches that need the
         two-stage metric reduction."""
         lib = L.lib()
         D, n = act.shape[0], act[0].numel()
@@ -279,8 +283,8 @@ class HipBackend(object):
         q = torch.empty(D, device=dev, dtype=torch.float32)
         m = out[1:]
         L.check(lib.dun_predict_gauss_step(L.f32(act), L.f32(q_logits), 1, D, n, L.f32(mean), L.f32(std), L.f32(y),
-                                           L.f32(log_std), L.ptr(m), L.ptr(m), L.f32(q), L.f32(objective), L.ptr(out),
-                                           L.stream_ptr(dev)), "dun_predict_gauss_step")
+                                           L.f32(log_std), L.out_ptr(m), L.out_ptr(m), L.f32(q), L.f32(objective),
+                                           L.out_ptr(out), L.stream_ptr(dev)), "dun_predict_gauss_step")
         return q
 
     # ---- trunk ----------------------------------------------------------------------------------------
@@ -360,6 +364,12 @@ class HipBackend(object):
     def sgd_step(self, p, g, buf, lr, momentum, weight_decay):
         L.check(L.lib().dun_sgd_step(L.f32(p), L.f32(g), L.f32(buf), p.numel(), float(lr), float(momentum),
                                      float(weight_decay), L.stream_ptr(p.device)), "dun_sgd_step")
+
+    def copy_pair(self, dst0, src0, dst1, src1):
+        """dst0 <- src0 and dst1 <- src1 (same shapes / dtypes, contiguous device tensors) in ONE launch."""
+        L.check(L.lib().dun_copy_pair(L.ptr(dst0), L.ptr(src0), dst0.numel() * dst0.element_size(), L.ptr(dst1),
+                                      L.ptr(src1), dst1.numel() * dst1.element_size(), L.stream_ptr(dst0.device)),
+                "dun_copy_pair")
 
     def sgd_step_multi(self, triples, lr, momentum, weight_decay):
         """The same update over several (param, grad, momentum buffer) triples, DUN_SGD_MAX_SEGMENTS per launch."""

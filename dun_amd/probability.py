@@ -129,7 +129,10 @@ def head_objective_spec(y, f_neg_loglike, objective, q_logits, batch, dist=None,
         fin = dict(objective=objective, q_logits=None if q_logits is None else q_logits.detach(),
                    logprior=finalize["logprior"].to(device=yy.device, dtype=torch.float32).contiguous(),
                    N_train=float(finalize["N_train"]), batch=float(gb), beta=float(finalize.get("beta", 1.0)),
-                   eps=float(finalize.get("eps", 1e-35)))
+                   eps=float(finalize.get("eps", 1e-35)),
+                   # the ELBO's d loss / d act needs no reduced quantity: its finalisation may wait for the backward's
+                   # weight-gradient launch; the exact marginal needs the posterior before its backward
+                   defer=bool(objective == OBJ_VI and want_grad))
     return HeadObjective(yy, w, True, f_neg_loglike.log_std.detach(), 1.0 / gb, fin)
 
 

@@ -112,7 +112,9 @@ class DUN(BaseNet):
             # regression on one device: predictor, metric sums, q(d) and the objective's copy in ONE launch
             step = getattr(be, "predict_step", None)
             if step is not None and self.regression and self._dist is None and objective is not None:
-                out = torch.empty(3, device=act.device, dtype=torch.float64)
+                # (a captured step hands over pinned host memory: the kernel's three doubles go home without a copy node)
+                pinned = self.__dict__.get("_metrics_out")
+                out = pinned[:3] if pinned is not None else torch.empty(3, device=act.device, dtype=torch.float64)
                 q = step(act, q_logits.detach(), y.to(torch.float32).contiguous(), self.f_neg_loglike.log_std.detach(),
                          objective.detach().reshape(1), out)
                 if q is not None:
@@ -207,21 +209,39 @@ class DUN(BaseNet):
             return self._metrics_host(*step_fn(x, y))
         states[key] = states.pop(key)  # most recently used last
         self._graph_state = st
-        if st["graph"] is not None:
-            st["x"].copy_(x, non_blocking=True)
-            st["y"].copy_(y, non_blocking=True)
-            st["graph"].replay()
-            self.prob_model.current_posterior = st["posterior"]
-            return self._metrics_host(st["m"], st["n"])
-        # second step with the same configuration: capture, then replay
-        sx, sy = x.clone(), y.clone()
-        graph = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(graph):
-            m, n = step_fn(sx, sy)
-        st.update(graph=graph, x=sx, y=sy, m=m, n=n, posterior=self.prob_model.current_posterior)
-        graph.replay()
-        return self._metrics_host(m, n)
+        if st["graph"] is None:
+            # second step with the same configuration: capture.  The returned scalars leave through a device -> pinned
+            # host copy INSIDE the graph, so a replayed step is: one input-copy launch, one graph launch, one stream wait
+            sx = x.contiguous().clone()
+            sy = y.contiguous().clone()
+            graph = torch.cuda.CUDAGraph()
+            pinned = torch.empty(8, dtype=torch.float64, pin_memory=True)  # (allocated outside the capture)
+            torch.cuda.synchronize()
+            self._metrics_out = pinned
+            try:
+                with torch.cuda.graph(graph):
+                    m, n = step_fn(sx, sy)
+                    host = m
+                    if m.is_cuda:  # (the metric kernels of this configuration write device memory)
+                        host = pinned[:m.numel()]
+                        host.copy_(m, non_blocking=True)
+            finally:
+                self._metrics_out = None
+            # the graph holds raw pointers into the trunk's activation buffers: keep them alive as long as the graph
+            # (the model's buffer cache evicts on its own schedule)
+            keep = list(getattr(self.model, "_fc_cache", {}).values())
+            st.update(graph=graph, x=sx, y=sy, m=m, n=n, host=host, posterior=self.prob_model.current_posterior, keep=keep)
+        else:
+            copy_pair = getattr(kernels.backend(), "copy_pair", None)
+            if copy_pair is not None and x.is_contiguous() and y.is_contiguous():
+                copy_pair(st["x"], x, st["y"], y)
+            else:
+                st["x"].copy_(x, non_blocking=True)
+                st["y"].copy_(y, non_blocking=True)
+        st["graph"].replay()
+        self.prob_model.current_posterior = st["posterior"]
+        torch.cuda.current_stream().synchronize()
+        return self._metrics_host(st["host"], st["n"])
 
     def _prior_loglikes(self):
         """model.get_w_prior_loglike(k=None); None (= the zeros the reference returns, src/DUN/stochastic_fc_models.py:52)

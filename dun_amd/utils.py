@@ -68,7 +68,8 @@ class BaseNet(object):
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        st.pop("_graph_state", None)  # captured hipGraphs do not pickle
+        for k in ("_graph_state", "_graph_states", "_metrics_out"):  # captured hipGraphs do not pickle
+            st.pop(k, None)
         st["_dist"] = None
         return st
 
@@ -94,6 +95,7 @@ class BaseNet(object):
         self.optimizer = state["optimizer"]
         self.scheduler = state["scheduler"]
         self.__dict__.pop("_graph_state", None)
+        self.__dict__.pop("_graph_states", None)
         print("  restoring epoch: %d, lr: %f" % (self.epoch, self.lr))
         if "best_err" in state:
             return self.epoch, state["best_err"]

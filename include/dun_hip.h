@@ -267,6 +267,11 @@ typedef struct dun_fc_ctx {
     const float* obj_fin_prior_ll;  /* [depth+1] or NULL */
     double obj_fin_N_train, obj_fin_batch, obj_fin_beta, obj_fin_eps;
     int obj_fin_objective;          /* DUN_OBJ_VI / DUN_OBJ_MLL */
+    /* 1: dun_fc_forward only leaves the partial sums and dun_fc_backward(c) -- same context, called next -- finishes the
+     * objective in a spare workgroup of its weight-gradient launch, off every critical path (the variational
+     * objective: its d loss / d act needs no reduced quantity, so nothing before the optimiser reads the result block;
+     * the exact marginal needs the posterior before its backward and must not defer). */
+    int obj_fin_defer;
 } dun_fc_ctx;
 
 size_t dun_fc_workspace_floats(int B, int din, int W, int O, int L);
@@ -297,7 +302,8 @@ int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream);  /* whole net, Bat
 int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream); /* whole net, needs a train-mode forward */
 int dun_fc_small_net_mode(int mode);
 size_t dun_fc_sync_bytes(int B, int W); /* size of dun_fc_ctx.sync for this shape (0: shape never takes mode 2) */
-/* 1 when dun_fc_forward(c) will also finish the objective (obj_fin_* set and the forward is one launch). */
+/* 1 when dun_fc_forward(c) -- or, with obj_fin_defer, the dun_fc_backward(c) that follows it -- will also finish the
+ * objective (obj_fin_* set and the forward is one launch). */
 int dun_fc_objective_in_forward(const dun_fc_ctx* c);
 /* Error word of the one-launch kernels, read back from c->sync (HOST call, synchronises the stream): 0, or the code of
  * the exchange that gave up waiting for another workgroup (bounded spins; the outputs of such a call are NaN). */
@@ -359,6 +365,11 @@ typedef struct dun_sgd_segment {
 } dun_sgd_segment;
 int dun_sgd_step_multi(const dun_sgd_segment* segments /* host array */, int nseg, float lr, float momentum,
                        float weight_decay, dun_stream_t stream);
+
+/* Two device-to-device copies in ONE launch (the inputs of a captured training step go into its static buffers:
+ * x and y of src/DUN/training_wrappers.py:215; host glue, no arithmetic).  Byte counts; any alignment. */
+int dun_copy_pair(void* dst0, const void* src0, size_t bytes0, void* dst1, const void* src1, size_t bytes1,
+                  dun_stream_t stream);
 
 #ifdef __cplusplus
 }

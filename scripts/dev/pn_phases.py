@@ -11,6 +11,24 @@ for _ in range(20):
 torch.cuda.synchronize()
 buf = net.model._get_buffers(512, 10, True)
 P = 32
+if len(sys.argv) > 1 and sys.argv[1] == "bwd":
+    # the last launch that stamped was the backward: same stamp area
+    raw = buf.sync.view(torch.int32)[64:].view(2, P, 128, 4)[:, :, 104:, :].contiguous().view(torch.int64).view(2, P, 48)
+    st = torch.cat([raw[0], raw[1]], dim=1).cpu().double()
+    for pid in (0, 15, 31):
+        s = st[pid]
+        print("wg %d: prologue %.2f us" % (pid, (s[1] - s[90]) / 100))
+        for ph in range(10):
+            b = 1 + 5 * ph
+            nxt = s[b + 5] if ph < 9 else s[94]
+            print("  phase %d: stats %.2f  publish+gather %.2f  prefetch+dU+store %.2f  barrier %.2f  mm+update %.2f | t=%.2f"
+                  % (ph, (s[b + 1] - s[b]) / 100, (s[b + 2] - s[b + 1]) / 100, (s[b + 3] - s[b + 2]) / 100,
+                     (s[b + 4] - s[b + 3]) / 100, (nxt - s[b + 4]) / 100, (s[b] - s[90]) / 100))
+        print("  total %.2f us" % ((s[94] - s[90]) / 100))
+    sys.exit(0)
+from dun_amd import kernels
+kernels.backend().fc_forward(buf)  # (the backward stamps the same area: run the forward once more, same launch as in fit)
+torch.cuda.synchronize()
 raw = buf.sync.view(torch.int32)[64:].view(2, P, 128, 4)[:, :, 104:, :].contiguous().view(torch.int64).view(2, P, 48)
 st = torch.cat([raw[0], raw[1]], dim=1).cpu().double()  # [P, 96]
 for pid in (0, 15, 31):

@@ -121,3 +121,13 @@ def test_state_before_the_first_step_and_rejections(cpu_backend, tmp_path):
     with pytest.raises(ValueError, match="parameters"):
         quiet(small.load_state, os.path.join(GOLDEN, "ckpt_ref_vi.pt"))
     assert torch.equal(before, small.model.flat_params)  # refused before anything was overwritten
+    # same parameter COUNT, another width: also refused before the first byte is overwritten (hyper-parameters included)
+    wide = build(dict(c.cfg, W=c.cfg["W"] + 4), seed=9)
+    before = wide.model.flat_params.clone()
+    lr_before = wide.optimizer.param_groups[0]["lr"]
+    q_before = wide.prob_model.q_logits.detach().clone()
+    with pytest.raises(ValueError, match="shape"):
+        quiet(wide.load_state, os.path.join(GOLDEN, "ckpt_ref_vi.pt"))
+    assert torch.equal(before, wide.model.flat_params) and torch.equal(q_before, wide.prob_model.q_logits.detach())
+    assert wide.optimizer.param_groups[0]["lr"] == lr_before
+

@@ -500,6 +500,31 @@ def test_graphed_steps_with_a_ragged_last_batch(monkeypatch):
     assert torch.equal(net.prob_model.current_posterior, eager.prob_model.current_posterior)
 
 
+def test_captured_steps_outlive_the_models_buffer_cache(monkeypatch):
+    """More distinct batch sizes than either cache holds (four captured steps per wrapper, four buffer sets per model,
+    evicted on different schedules): a captured step keeps the activation buffers it was captured on alive, so
+    returning to the first batch size replays onto valid memory -- the trajectory equals the eager one bit for bit."""
+    c = Case("c2_boston")
+    x, y = c.t("x").cuda(), c.y().cuda()
+    sizes = [64, 80, 96, 112, 128, 144]
+    order = [s for s in sizes for _ in range(2)] + [64, 64, 80, 144, 64]
+    monkeypatch.setenv("DUN_NO_GRAPH", "1")
+    eager = build_net(c)
+    want = [eager.fit(x[:n], y[:n]) for n in order]
+    monkeypatch.delenv("DUN_NO_GRAPH")
+    net = build_net(c)
+    got = []
+    for n in order:
+        got.append(net.fit(x[:n], y[:n]))
+        junk = torch.randn(1 << 16, device="cuda")  # whatever the allocator hands out next is overwritten
+        del junk
+    assert np.array_equal(np.array(got), np.array(want), equal_nan=True), (got, want)
+    assert torch.equal(net.model.flat_params, eager.model.flat_params)
+    for st in net._graph_states.values():
+        if st["graph"] is not None:
+            assert len(st["keep"]) > 0
+
+
 def test_train_fc_epoch_loop_on_device_loader(tmp_path):
     """Config-1 end to end on the GPU: the reference-shaped epoch loop over a device-resident loader."""
     from dun_amd.datasets import DeviceLoader, load_wiggle

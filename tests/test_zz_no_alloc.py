@@ -31,11 +31,25 @@ def _both(lib, L, D, B, seed, with_prior):
     res_st = torch.full_like(res_ws, float("nan"))
     dact_st = torch.full_like(act, float("nan"))
     torch.cuda.synchronize()
-    free_before = torch.cuda.mem_get_info()[0]
+    # the call takes no device memory: this process's allocator state is unchanged across it (device-wide free memory
+    # would also see other processes), and it runs under stream capture, which fails on any allocation -- the use case
+    # the entry exists for
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        L.check(lib.dun_elbo_gauss_static(L.f32(act), L.f32(y), L.f32(ls), L.f32(ql), L.f32(logprior), pr, D, B, N, 1.0,
+                                          1e-35, L.f32(dact_st), L.f32(res_st), L.stream_ptr(act.device)),
+                "dun_elbo_gauss_static (captured)")
+    assert bool(torch.isnan(res_st).all())                   # captured, not run
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(res_st, res_ws) and torch.equal(dact_st, dact_ws), (D, B, "replayed")
+    res_st.fill_(float("nan")); dact_st.fill_(float("nan"))
+    torch.cuda.synchronize()
+    alloc_before, reserved_before = torch.cuda.memory_allocated(), torch.cuda.memory_reserved()
     L.check(lib.dun_elbo_gauss_static(L.f32(act), L.f32(y), L.f32(ls), L.f32(ql), L.f32(logprior), pr, D, B, N, 1.0,
                                       1e-35, L.f32(dact_st), L.f32(res_st), sp), "dun_elbo_gauss_static")
     torch.cuda.synchronize()
-    assert torch.cuda.mem_get_info()[0] == free_before      # the call took no device memory
+    assert torch.cuda.memory_allocated() == alloc_before and torch.cuda.memory_reserved() == reserved_before
     assert bool(torch.isfinite(res_ws).all()) and bool(torch.isfinite(dact_ws).all())
     assert torch.equal(res_st, res_ws) and torch.equal(dact_st, dact_ws), (D, B)
 
