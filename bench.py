@@ -174,8 +174,7 @@ def gemm_kernel_name(M, N, K, a_kc, b_kc, plain_few_tiles=False):
     """Which GEMM kernel the library dispatches for this shape (dun_amd/csrc/gemm.hip: gemm_f32)."""
     small = ((M + 127) // 128) * ((N + 127) // 128) < 128
     if not small and M % 128 == 0 and N % 128 == 0 and K % 32 == 0:
-        wide = (os.environ.get("DUN_GEMM_WIDE", "1")[:1] != "0" and N % 256 == 0 and (M // 128) * (N // 256) >= 512
-                and not plain_few_tiles and (a_kc or not b_kc))
+        wide = N % 256 == 0 and (M // 128) * (N // 256) >= 512 and not plain_few_tiles and (a_kc or not b_kc)
         if wide:
             return "gemm_f32_wide_kernel<A_KC=%d,B_KC=%d> (128x256 tiles)" % (a_kc, b_kc)
         return "gemm_f32_dma4_kernel<A_KC=%d,B_KC=%d>" % (a_kc, b_kc)
@@ -184,32 +183,93 @@ def gemm_kernel_name(M, N, K, a_kc, b_kc, plain_few_tiles=False):
 
 
 def small_net_path(B, W):
-    """Mirror of sn_shape_ok (dun_amd/csrc/smallnet.hip): does dun_fc_forward/backward run the column-owned
-    one-launch-per-block kernels for this shape?"""
-    return os.environ.get("DUN_SMALLNET", "1")[:1] != "0" and 4 <= W <= 128 and W % 4 == 0 and 1 <= B <= 2048
+    """Mirror of sn_shape_ok (dun_amd/csrc/smallnet.hip): does dun_fc_forward/backward leave the tiled-GEMM path for
+    this shape (mode 1: one launch per block, mode 2: one launch per pass; dun_fc_small_net_mode)?"""
+    from dun_amd import _lib
+    return _lib.lib().dun_fc_small_net_mode(-1) != 0 and 4 <= W <= 128 and W % 4 == 0 and 1 <= B <= 2048
 
 
 def small_net_rooflines(net, B_local, reps):
-    """Small nets: the step's trunk is L one-launch block forwards + L+1 one-launch backwards (vector ALUs, latency
-    bound).  Timed live on the step's own buffers through the C entries; flop rates are reported for scale only."""
-    from dun_amd import kernels
+    """Small nets: the step's trunk is ONE launch forward and ONE backward + one weight-gradient launch (persist.hip;
+    latency bound: a chain of per-block BatchNorm exchanges).  Timed live on the step's own buffers through the C
+    entries; flop rates are reported for scale only."""
+    from dun_amd import _lib, kernels
     be = kernels.backend()
     model = net.model
     W, L = model.width, model.n_layers
     buf = model._get_buffers(B_local, L, True)
     buf.ensure_backward()
-    rm, rv = model.running_mean.clone(), model.running_var.clone()
+    if buf.dact is None:
+        buf.set_dact(torch.zeros(L + 1, B_local, 1, device=buf.H.device))
+    rm, rv, nbt = model.running_mean.clone(), model.running_var.clone(), model.num_batches_tracked.clone()
     fwd = timed(lambda: be.fc_forward(buf), reps)
     bwd = timed(lambda: be.fc_backward(buf), reps)
     model.running_mean.copy_(rm)
     model.running_var.copy_(rv)
+    model.num_batches_tracked.copy_(nbt)
+    mode = _lib.lib().dun_fc_small_net_mode(-1)
     f_fwd = 2.0 * B_local * (L * W * W + model.input_dim * W + (L + 1) * W)
+    how = ("pn_forward_kernel: whole dun_fc_forward in ONE launch (row-owning workgroups, f32 MFMA 16x16x4 tiles, tagged-"
+           "record BatchNorm exchange)" if mode == 2 and model.output_dim == 1 else
+           "sn_block_fwd_kernel x%d (+ input GEMM, head): whole dun_fc_forward, column-owned block kernels" % L)
     return {
-        "gemm_fwd": dict(kernel="sn_block_fwd_kernel x%d (+ input GEMM, head): whole dun_fc_forward, column-owned block "
-                                "kernels on the vector ALUs" % L, ms=fwd, tflops=f_fwd / fwd / 1e9),
-        "trunk_backward": dict(kernel="sn_block_bwd_kernel x%d (+ head backward): whole dun_fc_backward" % (L + 1),
+        "gemm_fwd": dict(kernel=how, ms=fwd, tflops=f_fwd / fwd / 1e9),
+        "trunk_backward": dict(kernel="whole dun_fc_backward (%s)" % ("pn_backward_kernel + pn_dw_kernel" if mode == 2 else
+                                                                      "sn_block_bwd_kernel x%d" % (L + 1)),
                                ms=bwd, tflops=2.0 * f_fwd / bwd / 1e9),
     }
+
+
+def gemm_in_step(net, x, y, B_local):
+    """ONE real training step with every GEMM launch bracketed by HIP events on its own stream (dun_gemm_profile_begin /
+    _end): per-launch milliseconds of the trunk's three GEMM classes as the step runs them.  -> dict or None."""
+    import ctypes as C
+    from dun_amd import _lib
+    lib = _lib.lib()
+    W, L = net.model.width, net.model.n_layers
+    cap = 4 * (3 * L + 8)
+    if lib.dun_gemm_profile_begin(cap) != 0:
+        return None
+    try:
+        net.fit(x, y)
+    finally:
+        recs = (_lib.GemmProfileRec * cap)()
+        n = lib.dun_gemm_profile_end(recs, cap)
+    cls = {"fwd": [], "dx": [], "dw": []}
+    for r in recs[:n]:
+        if r.M == B_local and r.N == W and r.K == W and (r.epilogue & 2):
+            cls["fwd"].append(r.ms)
+        elif r.M == B_local and r.N == W and r.K == W and (r.epilogue & (4 | 8)):
+            cls["dx"].append(r.ms)
+        elif r.M == W and r.N == W and r.K == B_local:
+            cls["dw"].append(r.ms)
+    flops = 2.0 * B_local * W * W
+    out = {}
+    for k, v in cls.items():
+        if v:
+            ms = sum(v) / len(v)
+            out[k] = {"launches": len(v), "ms_per_launch": ms, "tflops": flops / ms / 1e9,
+                      "frac": flops / ms / 1e9 / MFMA_F32_PEAK_TF}
+    return out or None
+
+
+def secondary_c2(steps=500, warmup=30):
+    """BASELINE.json configs[1] (UCI-shaped net, batch 512) timed by the same process: value and ms/step."""
+    din, W, L, B, N_train, lr, momentum, wd = WORKLOADS["c2_uci"]
+    net = build_net(din, W, L, N_train, lr, momentum, wd)
+    x, y = shard_data(B, din, 0, torch.device("cuda", torch.cuda.current_device()))
+    for _ in range(warmup):
+        last = net.fit(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = net.fit(x, y)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "c2_uci: regression DUN_VI.fit, residual MLP %d blocks x width %d, din %d, batch %d, N_train %d, "
+                        "SGD(lr %g, momentum %g); whole step captured as one hipGraph" % (L, W, din, B, N_train, lr, momentum),
+            "metric": "DUN ELBO train samples/sec", "value": B * steps / dt, "unit": "samples/s",
+            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "finite": all(math.isfinite(v) for v in last)}
 
 
 def kernel_rooflines(net, B_local, reps, y=None):
@@ -347,6 +407,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-sync-bn", action="store_true", help="per-replica BatchNorm statistics (not matched numerics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c2_uci figure the c3_wide line carries")
     ap.add_argument("--cpu-batch", type=int, default=0)
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="one-GPU rehearsal of the N>1 branch of this script: a one-rank RCCL group, the sharded step "
@@ -561,7 +622,12 @@ def run_rank(args):
         return
 
     last = None
+    in_step = None
     for i in range(args.warmup):
+        if (not image and not cpu and rank == 0 and i == args.warmup - 1 and not args.no_kernel_rooflines
+                and not small_net_path(B_local, W)):
+            in_step = gemm_in_step(net, x, y, B_local)  # (this warm-up step runs with its GEMM launches timed)
+            continue
         last = net.fit(x, y)
         if image and rank == 0:
             dev_sync()
@@ -630,7 +696,21 @@ def run_rank(args):
         result["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                               "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_F32_PEAK_TF,
                               "traffic": pmc_traffic("gemm_fwd", args.workload, world), "ms_per_launch": dom["ms"],
-                              "flop_per_launch": 2.0 * B_local * W * W}
+                              "flop_per_launch": 2.0 * B_local * W * W,
+                              "timing": "back-to-back launches of the kernel on the step's buffers (HIP events)"}
+        if result["roofline"]["traffic"] is not None:
+            result["roofline"]["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 PMC passes of an earlier run of this "
+                                                    "workload (2*FETCH_SIZE + WRITE_SIZE per launch), NOT measured by this run")
+        if in_step and "fwd" in in_step:
+            # the figure the step is made of: the same kernel timed inside a real training step (a warm-up step of this
+            # run, every GEMM launch bracketed by HIP events); the back-to-back figure stays beside it
+            live = dict(achieved=result["roofline"]["achieved"], frac=result["roofline"]["frac"],
+                        ms_per_launch=result["roofline"]["ms_per_launch"])
+            f = in_step["fwd"]
+            result["roofline"].update(achieved=f["tflops"], frac=f["frac"], ms_per_launch=f["ms_per_launch"],
+                                      timing="inside a real training step of this run: HIP events around each of the %d "
+                                             "forward GEMM launches (dun_gemm_profile_begin/_end)" % f["launches"],
+                                      back_to_back=live, in_step=in_step)
         if small:  # latency-bound regime: the figure is whole-forward flops, not a roofline claim
             result["roofline"]["flop_per_launch"] = dom["tflops"] * dom["ms"] * 1e9
             result["roofline"]["note"] = "small net: launch/latency bound, fp32 vector ALUs; fraction of the f32 matrix peak shown for scale only"
@@ -640,6 +720,8 @@ def run_rank(args):
                 {"bound": "hbm", "achieved": v["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": v["gbs"] / HBM_PEAK_GBS, "ms_per_launch": v["ms"]})
             for k, v in kr.items() if k != "gemm_fwd"}
+    if rank == 0 and world == 1 and not cpu and args.workload == "c3_wide" and not args.no_secondary:
+        result["secondary"] = secondary_c2()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         # free the GPU-side buffers' host shadows are irrelevant; the oracle runs on the host cores only
         B_cpu = args.cpu_batch or (2048 if args.workload == "c3_wide" else B)

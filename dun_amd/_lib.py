@@ -24,6 +24,7 @@ EXPORTS = [
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
     "dun_sgd_step_multi", "dun_predict_gauss_step", "dun_fc_small_net_mode", "dun_fc_sync_bytes", "dun_fc_sync_status",
     "dun_fc_objective_in_forward", "dun_fc_head_grads_in_forward", "dun_copy_pair",
+    "dun_copy_pair_indirect", "dun_predict_gauss_step_signal", "dun_gemm_profile_begin", "dun_gemm_profile_end",
 ]
 
 SGD_MAX_SEGMENTS = 24
@@ -44,6 +45,11 @@ class GemmDesc(C.Structure):
                 ("colstats", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_size_t),
                 ("bnz", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_rstd", C.c_void_p), ("bnstats", C.c_void_p),
                 ("ldz", C.c_int)]
+
+
+class GemmProfileRec(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("M", "N", "K", "a_kcontig", "b_kcontig", "epilogue", "kernel", "ksplit")] + \
+               [("ms", C.c_float)]
 
 
 class FcTensors(C.Structure):
@@ -128,6 +134,10 @@ def _declare(lib):
         "dun_fc_objective_in_forward": (i, [C.POINTER(FcCtx)]),
         "dun_fc_head_grads_in_forward": (i, [C.POINTER(FcCtx)]),
         "dun_copy_pair": (i, [vp, vp, sz, vp, vp, sz, vp]),
+        "dun_gemm_profile_begin": (i, [i]),
+        "dun_gemm_profile_end": (i, [C.POINTER(GemmProfileRec), i]),
+        "dun_copy_pair_indirect": (i, [vp, sz, vp, sz, vp, vp]),
+        "dun_predict_gauss_step_signal": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
                                                             double* __restrict__ partials, int nparts,
                                                             int q_is_logits, float* __restrict__ q_out,
                                                             const float* __restrict__ obj_src,
-                                                            double* __restrict__ obj_dst) {
+                                                            double* __restrict__ obj_dst, double* done) {
     __shared__ double red[4];
     __shared__ float s_q[256];
     const int tid = threadIdx.x;
@@ -599,6 +599,10 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
             partials[blockIdx.x] = t0;
             partials[nparts + blockIdx.x] = t1;
         }
+    }
+    if (done != nullptr && tid == 0 && blockIdx.x == 0) {  // (one-workgroup launches only: this thread wrote every scalar)
+        __threadfence_system();
+        __hip_atomic_store(done, 1.0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1125,25 +1129,29 @@ extern "C" int dun_elbo_gauss_static(const float* act, const float* y, const flo
 
 static int predict_gauss_impl(const float* act, const float* q, int q_is_logits, int D, int n, float* mean, float* std,
                               const float* y, const float* log_std, double* partials, double* metrics, float* q_out,
-                              const float* obj_src, double* obj_dst, dun_stream_t stream, const char* who) {
+                              const float* obj_src, double* obj_dst, double* done, dun_stream_t stream, const char* who) {
     DUN_REQUIRE(act && q && mean, "%s: null pointer", who);
     DUN_REQUIRE(D > 0 && n > 0, "%s: empty input", who);
     DUN_REQUIRE(metrics == nullptr || (y && log_std && partials), "%s: metrics need y, log_std, partials", who);
     DUN_REQUIRE((obj_src == nullptr) == (obj_dst == nullptr), "%s: objective_src and objective_dst go together", who);
     const int nparts = dun_predict_num_partials(n, 1);
+    if (done != nullptr && nparts != 1) {
+        set_error("%s: the completion word needs a one-workgroup predictor (n = %d)", who, n);
+        return DUN_ERR_UNSUPPORTED;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     // one workgroup: its [2][1] partials ARE the metric sums, no reduction launch
     double* part = metrics ? (nparts == 1 ? metrics : partials) : nullptr;
     const bool vec = (n % 4 == 0) && aligned16(act);
     if (vec && stream_nt((size_t)D * n * 4))
         hipLaunchKernelGGL((predict_gauss_kernel<true, true>), dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done);
     else if (vec)
         hipLaunchKernelGGL(predict_gauss_kernel<true>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done);
     else
         hipLaunchKernelGGL(predict_gauss_kernel<false>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done);
     DUN_LAUNCH_CHECK();
     if (metrics && nparts > 1) {
         hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);
@@ -1155,8 +1163,8 @@ static int predict_gauss_impl(const float* act, const float* q, int q_is_logits,
 extern "C" int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std,
                                  const float* y, const float* log_std, double* partials, double* metrics,
                                  dun_stream_t stream) {
-    return predict_gauss_impl(act, q, 0, D, n, mean, std, y, log_std, partials, metrics, nullptr, nullptr, nullptr, stream,
-                              "dun_predict_gauss");
+    return predict_gauss_impl(act, q, 0, D, n, mean, std, y, log_std, partials, metrics, nullptr, nullptr, nullptr, nullptr,
+                              stream, "dun_predict_gauss");
 }
 
 extern "C" int dun_predict_gauss_step(const float* act, const float* q, int q_is_logits, int D, int n, float* mean,
@@ -1164,7 +1172,16 @@ extern "C" int dun_predict_gauss_step(const float* act, const float* q, int q_is
                                       float* q_out, const float* objective_src, double* objective_dst,
                                       dun_stream_t stream) {
     return predict_gauss_impl(act, q, q_is_logits, D, n, mean, std, y, log_std, partials, metrics, q_out, objective_src,
-                              objective_dst, stream, "dun_predict_gauss_step");
+                              objective_dst, nullptr, stream, "dun_predict_gauss_step");
+}
+
+extern "C" int dun_predict_gauss_step_signal(const float* act, const float* q, int q_is_logits, int D, int n, float* mean,
+                                             float* std, const float* y, const float* log_std, double* metrics,
+                                             float* q_out, const float* objective_src, double* objective_dst, double* done,
+                                             dun_stream_t stream) {
+    DUN_REQUIRE(metrics != nullptr && done != nullptr, "dun_predict_gauss_step_signal: null metrics / done");
+    return predict_gauss_impl(act, q, q_is_logits, D, n, mean, std, y, log_std, metrics, metrics, q_out, objective_src,
+                              objective_dst, done, stream, "dun_predict_gauss_step_signal");
 }
 
 extern "C" int dun_predict_softmax(const float* act, const float* q, int D, int B, int C, float* probs,

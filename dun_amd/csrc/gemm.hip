@@ -2,14 +2,12 @@
 //
 // C[M,N] = epi(sum_k A(m,k) B(k,n)) on v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), so the
 // trunk keeps the reference's fp32 numerics (north-star: 1e-5 relative) while running on the matrix cores.
-// Four kernels share one epilogue:
+// Three kernels share one epilogue:
 //   gemm_f32_wide_kernel  whole 128x256 tiles, >= 512 of them, no split-K (the wide config's forward and dX GEMMs): the
 //                         LDS-DMA pipeline below on three stages with 2x4 accumulators per wave;
 //   gemm_f32_dma4_kernel  whole 128x128 tiles, 16-byte aligned operands, >= 128 tiles (every trunk GEMM of the wide
 //                         config): LDS-DMA staging through four 16-deep stages, mid-tile barrier, counted waits,
 //                         optional split-K (see the comment above the kernel);
-//   gemm_f32_dma_kernel   the same problems with two 32-deep buffers and the barrier at the tile end (A/B reference,
-//                         and operands beyond 32-bit byte offsets);
 //   gemm_f32_kernel       everything else (ragged, unaligned, or too small to fill the chip): operand tiles staged
 //                         global -> registers -> LDS, double buffered, one barrier per K tile; 128x128 tiles or, under
 //                         128 tiles, 64x64 tiles; optional split-K.
@@ -55,7 +53,6 @@ struct GemmP {
     int gridM, gridN;
     int ksplit;   // > 1: blockIdx.y takes K range [y*K/ksplit, (y+1)*K/ksplit) and stores its raw sum to part[y]
     float* part;  // [ksplit][M][N]
-    int gm;       // LDS-DMA kernel: row panels per tile group (1: tiles of one row panel are consecutive)
     int rinit;    // LDS-DMA kernel: accumulators start from R (loaded under the pipeline prologue), not added at the end
     int wide;     // 128 x 256 tiles (gemm_f32_wide_kernel): gridN counts 256-column tiles
 };
@@ -468,119 +465,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Fast path for tile-aligned problems (M%128 == N%128 == K%32 == 0, 16-byte aligned rows): operand tiles go
-// HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), no VGPR round trip and no ds_write.  A wave-instruction
-// writes 1 KiB of LDS linearly (wave-uniform base + lane*16), so the images are unpadded:
-//   K-contiguous tile  [128 rows][32 k] = 128-B rows.  Bank-conflict-free ds_read_b128 comes from an XOR
-//     swizzle of the 16-B chunk index with (row>>1)&7, applied to the per-lane SOURCE address on the way in
-//     and to the read address on the way out (the same involution on both sides);
-//   M/N-contiguous tile [32 k][128] = 512-B rows, read with ds_read_b32 (32 lanes on 32 consecutive banks).
-// Two 32 KiB buffers; the DMA of tile t+1 is issued before the 64 MFMAs of tile t and retired by the
-// vmcnt(0) that __syncthreads() carries at the end of the tile.  64 KiB LDS -> two workgroups per CU.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int DMA_TILE = BM * BK;  // 4096 floats = 16 KiB per operand
-
-template <bool KC>
-__device__ __forceinline__ void dma_tile(const float* __restrict__ P, int ld, int r0, int k0, float* lds, int wave,
-                                         int lane) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int piece = wave * 4 + j;  // 1 KiB piece of the 16 KiB image
-        const float* src;
-        if (KC) {
-            const int row = piece * 8 + (lane >> 3), pc = lane & 7;
-            const int c = pc ^ ((row >> 1) & 7);
-            src = P + (size_t)(r0 + row) * ld + k0 + c * 4;
-        } else {
-            const int k = piece * 2 + (lane >> 5), col = (lane & 31) * 4;
-            src = P + (size_t)(k0 + k) * ld + r0 + col;
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(lds + piece * 256), 16, 0, 0);
-    }
-}
-
-template <bool KC>
-__device__ __forceinline__ void read_frag_dma(const float* lds, int row, int t, int h, float (&f)[4]) {
-    if (KC) {
-        const int pc = (2 * t + h) ^ ((row >> 1) & 7);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * BK + pc * 4);
-        f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f[e] = lds[(8 * t + 4 * h + e) * BM + row];
-    }
-}
-
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmP p) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * DMA_TILE];  // [buffer][A image | B image]
-
-    const int nwg = p.gridM * p.gridN;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = bid / p.gridN, bn = bid % p.gridN;
-    const int m0 = bm * BM, n0 = bn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases live in M0
-    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
-
-    f32x16 acc[2][2];
-    seed_acc<true, 2>(p, acc, m0, n0, wr, wc, li, h);
-
-    const int nk = p.K / BK;
-    dma_tile<A_KC>(p.A, p.lda, m0, 0, smem, wave, lane);
-    dma_tile<B_KC>(p.B, p.ldb, n0, 0, smem + DMA_TILE, wave, lane);
-    __syncthreads();  // carries the vmcnt(0) that retires the DMA
-
-    float fa[2][2][4], fb[2][2][4];
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const float* a_s = smem + cur * (2 * DMA_TILE);
-        const float* b_s = a_s + DMA_TILE;
-        if (kt + 1 < nk) {
-            // buffer cur^1 was last read in iteration kt-1, which every wave left through the barrier below
-            float* nxt = smem + (cur ^ 1) * (2 * DMA_TILE);
-            dma_tile<A_KC>(p.A, p.lda, m0, (kt + 1) * BK, nxt, wave, lane);
-            dma_tile<B_KC>(p.B, p.ldb, n0, (kt + 1) * BK, nxt + DMA_TILE, wave, lane);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) read_frag_dma<A_KC>(a_s, wr * 64 + mi * 32 + li, 0, h, fa[0][mi]);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) read_frag_dma<B_KC>(b_s, wc * 64 + ni * 32 + li, 0, h, fb[0][ni]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t < 3) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    read_frag_dma<A_KC>(a_s, wr * 64 + mi * 32 + li, t + 1, h, fa[(t + 1) & 1][mi]);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    read_frag_dma<B_KC>(b_s, wc * 64 + ni * 32 + li, t + 1, h, fb[(t + 1) & 1][ni]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][mi][e], fb[t & 1][ni][e],
-                                                                           acc[mi][ni], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Four-stage variant of the LDS-DMA kernel.  The two-buffer kernel above ends every 32-deep K tile with a barrier that
-// every wave reaches with an EMPTY matrix pipe (its MFMAs are issued, the next tile's fragments cannot be read before
-// the barrier), so each tile pays barrier skew + an LDS round trip.  Here the K loop advances in 16-deep half tiles
-// through a ring of four 16 KiB stages (same 64 KiB, still two workgroups per CU) and the barrier sits in the MIDDLE
-// of a half tile, behind 16 issued MFMAs:
+// Fast path for tile-aligned problems (M%128 == N%128 == K%32 == 0, 16-byte aligned rows): operand tiles go HBM/L2 -> LDS by
+// LDS-DMA (buffer_load ... lds, 16 B per lane), no VGPR round trip and no ds_write.  A wave-instruction writes 1 KiB of LDS
+// linearly (wave-uniform base + lane*16), so the images are unpadded and the bank-conflict swizzle of the K-contiguous image
+// is applied to the per-lane SOURCE address on the way in and undone on the read (the same involution on both sides).
+// The K loop advances in 16-deep half tiles through a ring of four 16 KiB stages (64 KiB, two workgroups per CU) and the
+// barrier sits in the MIDDLE of a half tile, behind 16 issued MFMAs (a first version with two 32-deep buffers ended every
+// tile with a barrier that every wave reached with an EMPTY matrix pipe: 82-87 % of peak against 91-92 %):
 //     half j:   [read frags (j, group 1)]  16 MFMAs (j, group 0)
 //               wait for the DMA of half j+1 (issued two half tiles ago; counted vmcnt, half j+2 stays in flight)
 //               s_barrier          -> half j+1 is visible to all waves; all waves are done reading half j-1
@@ -689,13 +580,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    int bm = bid / p.gridN, bn = bid % p.gridN;
-    if (p.gm > 1) {  // groups of gm row panels, row panel fastest inside a group
-        const int per = p.gm * p.gridN, g = bid / per, r = bid % per;
-        const int rows = min(p.gm, p.gridM - g * p.gm);
-        bm = g * p.gm + r % rows;
-        bn = r / rows;
-    }
+    // (tiles of one row panel are consecutive; grouping 4 / 8 / 16 row panels changed none of the three trunk GEMMs)
+    const int bm = bid / p.gridN, bn = bid % p.gridN;
     const int m0 = bm * BM, n0 = bn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1002,17 +888,9 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict
     }
 }
 
-// A/B hook: DUN_GEMM_NO_SPLITK=1 keeps long-K problems on one workgroup per tile
-static const bool g_no_splitk = getenv("DUN_GEMM_NO_SPLITK") != nullptr && getenv("DUN_GEMM_NO_SPLITK")[0] == '1';
-// A/B hook: DUN_GEMM_DMA2=1 keeps tile-aligned problems on the two-buffer LDS-DMA kernel
-static const bool g_dma_two_buffer = getenv("DUN_GEMM_DMA2") != nullptr && getenv("DUN_GEMM_DMA2")[0] == '1';
-
 template <bool A_KC, bool B_KC>
 static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream_t s) {
     const int grid = p.gridM * p.gridN;
-    // the four-stage kernel addresses its operands with 32-bit byte offsets from their bases
-    const bool fits32 = (long long)(A_KC ? p.M : p.K) * p.lda * 4 < (1ll << 31) &&
-                        (long long)(B_KC ? p.N : p.K) * p.ldb * 4 < (1ll << 31);
     if (p.wide) {
         hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
         if (p.ksplit > 1) {
@@ -1021,9 +899,7 @@ static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream
             const int g = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
             hipLaunchKernelGGL(splitk_sum_kernel, dim3(g), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
         }
-    } else if (dma && (g_dma_two_buffer || !fits32))
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
-    else if (dma && p.ksplit > 1) {
+    } else if (dma && p.ksplit > 1) {
         hipLaunchKernelGGL((gemm_f32_dma4_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
         DUN_LAUNCH_CHECK();
         const size_t n4 = (size_t)p.M * p.N / 4;
@@ -1052,18 +928,34 @@ static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream
     return DUN_OK;
 }
 
-// test hook: DUN_GEMM_GENERIC=1 in the environment keeps aligned problems on the register-staged kernel
-static const bool g_force_generic = getenv("DUN_GEMM_GENERIC") != nullptr && getenv("DUN_GEMM_GENERIC")[0] == '1';
-// test hook: DUN_GEMM_TILE128=1 keeps small problems on 128x128 tiles
-static const bool g_force_tile128 = getenv("DUN_GEMM_TILE128") != nullptr && getenv("DUN_GEMM_TILE128")[0] == '1';
-
 // fewer 128-tiles than half the CUs: take 64x64 tiles (UCI-sized nets are one to four 128-tiles per GEMM)
 static bool small_problem(int M, int N) {
-    return (long long)ceil_div(M, BM) * ceil_div(N, BN) < 128 && !g_force_tile128;
+    return (long long)ceil_div(M, BM) * ceil_div(N, BN) < 128;
 }
 
 // row tiles of an M x N problem = rows of the colstats partial matrix
 int gemm_colstat_tiles(int M, int N) { return ceil_div(M, small_problem(M, N) ? 64 : BM); }
+
+// measurement window of dun_gemm_profile_begin / _end (below)
+struct GemmProfSlot {
+    hipEvent_t a, b;
+    dun_gemm_profile_rec rec;
+};
+static GemmProfSlot* g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+static bool g_prof_on = false;
+
+static GemmProfSlot* gemm_profile_open(const dun_gemm_desc* d, int kernel, int ksplit, hipStream_t s) {
+    if (!g_prof_on || g_prof_n >= g_prof_cap) return nullptr;
+    GemmProfSlot* slot = &g_prof[g_prof_n++];
+    dun_gemm_profile_rec& r = slot->rec;
+    r.M = d->M; r.N = d->N; r.K = d->K;
+    r.a_kcontig = d->a_kcontig; r.b_kcontig = d->b_kcontig;
+    r.epilogue = (d->bias ? 1 : 0) | (d->relu ? 2 : 0) | (d->R ? 4 : 0) | (d->U ? 8 : 0) | (d->colstats ? 16 : 0) | (d->bnz ? 32 : 0);
+    r.kernel = kernel; r.ksplit = ksplit; r.ms = 0.f;
+    (void)hipEventRecord(slot->a, s);
+    return slot;
+}
 
 int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     DUN_REQUIRE(d != nullptr, "dun_gemm_f32: null descriptor");
@@ -1086,7 +978,6 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     p.bnz = d->bnz; p.bn_mean = d->bn_mean; p.bn_rstd = d->bn_rstd; p.bnstats = d->bnstats; p.ldz = d->ldz;
     DUN_REQUIRE(d->bnz == nullptr || (d->bn_mean && d->bn_rstd && d->bnstats && d->ldz >= d->N),
                 "dun_gemm_f32: bnz needs bn_mean, bn_rstd, bnstats and ldz >= N");
-    p.gm = 1;
     p.rinit = 0;
     p.wide = 0;
     const bool small = small_problem(d->M, d->N);
@@ -1103,21 +994,22 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     // matrix base: a matrix of 2 GiB or more (batch >= 262144 at width 2048) takes the register-staged kernel's flat path
     const auto below_2g = [&](int ld) { return ((long long)(d->M - 1) * ld + d->N) * 4 < (1ll << 31); };
     const bool out32 = below_2g(d->ldc) && (!d->R || below_2g(d->ldr)) && (!d->bnz || below_2g(d->ldz));
-    const bool dma = !small && vec && out32 && d->M % BM == 0 && d->N % BN == 0 && d->K % BK == 0 && !g_force_generic;
+    // ... and their operands by LDS-DMA with 32-bit byte offsets as well: operands of 2 GiB or more go the same way
+    const bool fits32 = (long long)(d->a_kcontig ? d->M : d->K) * d->lda * 4 < (1ll << 31) &&
+                        (long long)(d->b_kcontig ? d->N : d->K) * d->ldb * 4 < (1ll << 31);
+    const bool dma = !small && vec && out32 && fits32 && d->M % BM == 0 && d->N % BN == 0 && d->K % BK == 0;
     // One workgroup per CU cannot hide its own barriers: an epilogue-free problem with fewer tiles than 2 x 256 CUs and
     // a long K (dW = dU^T H: 256 tiles, K = batch) runs two K ranges per tile and adds them in a fixed order.
     p.ksplit = 1;
     p.part = nullptr;
     const long long tiles = (long long)p.gridM * p.gridN;
     const bool plain = !d->bias && !d->relu && !d->R && !d->U && !d->colstats && !d->bnz;
-    const bool fits32 = (long long)(d->a_kcontig ? d->M : d->K) * d->lda * 4 < (1ll << 31) &&
-                        (long long)(d->b_kcontig ? d->N : d->K) * d->ldb * 4 < (1ll << 31);
-    if (dma && plain && fits32 && !g_dma_two_buffer && !g_no_splitk && tiles < 512 && d->K % 64 == 0 && d->K >= 2048 &&
+    if (dma && plain && tiles < 512 && d->K % 64 == 0 && d->K >= 2048 &&
         d->splitk_ws != nullptr && d->splitk_ws_floats >= 2ull * d->M * d->N && aligned16(d->splitk_ws) &&
         aligned16(d->C) && d->ldc % 4 == 0) {
         p.ksplit = 2;
         p.part = d->splitk_ws;
-    } else if (!dma && plain && !g_no_splitk && d->splitk_ws != nullptr && aligned16(d->splitk_ws) && aligned16(d->C) &&
+    } else if (!dma && plain && d->splitk_ws != nullptr && aligned16(d->splitk_ws) && aligned16(d->C) &&
                d->ldc % 4 == 0 && d->N % 4 == 0) {
         // register-staged kernels (ragged or small problems, e.g. dW_in = G^T x: 32 tiles, K = batch; the 100-wide
         // UCI nets: 4 tiles, K = 512): one K range per 128 rows of K, as many as fill ~512 workgroups and fit the
@@ -1133,25 +1025,19 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
         }
     }
     {
-        // A/B hooks.  DUN_GEMM_GM=g: tiles ordered in groups of g row panels (measured at the wide configuration's shapes,
-        // g = 4, 8, 16: no change in any of the three GEMMs -- the kernels are not bound by L2 misses; default 1).
-        // DUN_GEMM_RINIT=0: residual added in the epilogue instead of seeding the accumulators (dX 3.94 -> 3.90 ms with
-        // the seeding, within 10 us of the epilogue-free kernel).
-        static const int env_gm = getenv("DUN_GEMM_GM") ? atoi(getenv("DUN_GEMM_GM")) : 1;
-        static const int env_rinit = getenv("DUN_GEMM_RINIT") ? atoi(getenv("DUN_GEMM_RINIT")) : 1;
-        p.gm = (dma && env_gm > 1) ? env_gm : 1;
+        // a residual seeds the accumulators (its loads go out in front of the pipeline prologue: dX 3.94 -> 3.90 ms at the
+        // wide configuration) wherever nothing runs between the contraction and the add
         const bool can_seed = d->R && !d->bias && !d->relu && p.ksplit == 1;
         if (d->bnz && (d->bias || d->relu || d->colstats || (d->R && !can_seed) || (d->U && d->O != 1))) {
             set_error("dun_gemm_f32: bnz together with bias / ReLU / colstats / a rank-O update with O > 1 is not implemented");
             return DUN_ERR_UNSUPPORTED;
         }
-        p.rinit = (can_seed && (env_rinit || d->bnz)) ? 1 : 0;  // (the statistics epilogue shares the residual's registers)
+        p.rinit = can_seed ? 1 : 0;
     }
     {
         // 128 x 256 tiles where they fill the chip without split-K (the trunk's forward and dX GEMMs): the per-tile
-        // prologue / store bubble is paid once per twice the work.  DUN_GEMM_WIDE=0 keeps 128 x 128 tiles.
-        static const int env_wide = getenv("DUN_GEMM_WIDE") ? atoi(getenv("DUN_GEMM_WIDE")) : 1;
-        if (env_wide && dma && fits32 && !g_dma_two_buffer && p.ksplit == 1 && d->N % WBN == 0 &&
+        // prologue / store bubble is paid once per twice the work.
+        if (dma && p.ksplit == 1 && d->N % WBN == 0 &&
             (long long)p.gridM * (d->N / WBN) >= 512 && d->K >= 64 && (!d->R || p.rinit) &&
             (!d->U || (d->O == 1 && !d->bias && !d->relu)) &&
             (d->a_kcontig || !d->b_kcontig)) {  // (the <M-contiguous, K-contiguous> instantiation spills: none of the trunk's GEMMs)
@@ -1159,12 +1045,14 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
             p.gridN = d->N / WBN;
         }
     }
-    if (d->a_kcontig) {
-        if (d->b_kcontig) return launch_gemm<true, true>(p, vec, dma, small, s);
-        return launch_gemm<true, false>(p, vec, dma, small, s);
-    }
-    if (d->b_kcontig) return launch_gemm<false, true>(p, vec, dma, small, s);
-    return launch_gemm<false, false>(p, vec, dma, small, s);
+    GemmProfSlot* slot = gemm_profile_open(d, p.wide ? 2 : (dma ? 1 : 0), p.ksplit, s);
+    int rc;
+    if (d->a_kcontig)
+        rc = d->b_kcontig ? launch_gemm<true, true>(p, vec, dma, small, s) : launch_gemm<true, false>(p, vec, dma, small, s);
+    else
+        rc = d->b_kcontig ? launch_gemm<false, true>(p, vec, dma, small, s) : launch_gemm<false, false>(p, vec, dma, small, s);
+    if (slot != nullptr) (void)hipEventRecord(slot->b, s);
+    return rc;
 }
 
 }  // namespace dun
@@ -1173,4 +1061,49 @@ extern "C" int dun_gemm_colstat_tiles(int M, int N) { return dun::gemm_colstat_t
 
 extern "C" int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream) {
     return dun::gemm_f32(desc, static_cast<hipStream_t>(stream));
+}
+
+// ---- measurement hook: duration of every GEMM launch INSIDE a real step (bench.py's roofline) ----------------------------
+// Between dun_gemm_profile_begin and dun_gemm_profile_end every dun_gemm_f32 call -- the trunk's own included -- is
+// bracketed by two HIP events on its stream; _end waits for them and hands back shape, flags and milliseconds per launch.
+// Off (no events, no overhead) outside that window.  Host-side state: one window at a time, not thread safe.
+
+extern "C" int dun_gemm_profile_begin(int max_launches) {
+    using namespace dun;
+    DUN_REQUIRE(!g_prof_on, "dun_gemm_profile_begin: a window is already open");
+    DUN_REQUIRE(max_launches > 0 && max_launches <= (1 << 16), "dun_gemm_profile_begin: 1 .. 65536 launches");
+    if (g_prof_cap < max_launches) {
+        GemmProfSlot* n = static_cast<GemmProfSlot*>(realloc(g_prof, sizeof(GemmProfSlot) * (size_t)max_launches));
+        DUN_REQUIRE(n != nullptr, "dun_gemm_profile_begin: out of host memory");
+        g_prof = n;
+        for (int i = g_prof_cap; i < max_launches; ++i) {
+            if (hipEventCreate(&g_prof[i].a) != hipSuccess || hipEventCreate(&g_prof[i].b) != hipSuccess) {
+                set_error("dun_gemm_profile_begin: hipEventCreate failed");
+                g_prof_cap = i;
+                return DUN_ERR_LAUNCH;
+            }
+        }
+        g_prof_cap = max_launches;
+    }
+    g_prof_n = 0;
+    g_prof_on = true;
+    return DUN_OK;
+}
+
+extern "C" int dun_gemm_profile_end(dun_gemm_profile_rec* out, int cap) {
+    using namespace dun;
+    if (!g_prof_on) return 0;
+    g_prof_on = false;
+    int n = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) != hipSuccess)
+            continue;
+        if (out != nullptr && n < cap) {
+            out[n] = g_prof[i].rec;
+            out[n].ms = ms;
+            ++n;
+        }
+    }
+    return n;
 }

@@ -600,7 +600,55 @@ __global__ __launch_bounds__(PN_T) void pn_forward_kernel(PnFwdP p) {
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
+// Work of the backward launch that sits on no critical path, done by ONE extra workgroup (index P) beside the row
+// owners: the head's weight / bias gradient from the partial sums the forward left ([P][W], [P]; fp64, fixed order) and
+// the depth-level finalisation of the objective the forward deferred (dun_depth_finalize_partials' arithmetic and
+// summation order).  Both read only what earlier launches wrote.
+struct PnSide {
+    const float *dwpart, *dbpart;  // NULL: the head gradients come from elsewhere
+    float *dw_out, *db_out;
+    int P, W;
+    float* fin_result;             // NULL: no deferred finalisation
+    int fin_D, fin_nparts, fin_objective;
+    const double* fin_partials;
+    double* fin_sums;
+    const float *fin_q_logits, *fin_logprior, *fin_prior_ll, *fin_log_std;
+    double fin_N, fin_batch, fin_beta, fin_eps;
+};
+
+__device__ __forceinline__ void pn_side_work(const PnSide& sd) {
+    __shared__ double s_side[512];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (sd.dwpart != nullptr) {
+        for (int c = wv; c <= sd.W; c += PN_T / 64) {  // column W: the bias gradient
+            double a = 0.0;
+            for (int q = lane; q < sd.P; q += 64) a += (double)(c < sd.W ? sd.dwpart[(size_t)q * sd.W + c] : sd.dbpart[q]);
+            a = wave_sum(a);
+            if (lane == 0) {
+                if (c < sd.W) sd.dw_out[c] = (float)a;
+                else sd.db_out[0] = (float)a;
+            }
+        }
+    }
+    if (sd.fin_result != nullptr) {
+        for (int d = wv; d < sd.fin_D; d += PN_T / 64) {
+            double a = 0.0;
+            for (int k = lane; k < sd.fin_nparts; k += 64) a += sd.fin_partials[(size_t)d * sd.fin_nparts + k];
+            a = wave_sum(a);
+            if (lane == 0) {
+                s_side[d] = a;
+                if (sd.fin_sums) sd.fin_sums[d] = a;
+            }
+        }
+        __syncthreads();
+        if (wv == 0)
+            depth_finalize_body(s_side, 1, sd.fin_q_logits, sd.fin_logprior, sd.fin_prior_ll, sd.fin_log_std, sd.fin_D,
+                                sd.fin_N, sd.fin_batch, sd.fin_beta, sd.fin_eps, sd.fin_objective, sd.fin_result);
+    }
+}
+
 struct PnBwdP {
+    PnSide side;
     int B, W, L, residual, P;
     const float *w, *w_out, *gamma;
     const float *Z, *bn_mean, *bn_rstd;
@@ -620,6 +668,10 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int pid = blockIdx.x, r0 = pid * PN_R;
+    if (pid == p.P) {  // the extra workgroup (launched only when there is side work)
+        pn_side_work(p.side);
+        return;
+    }
     const int B = p.B, W = p.W, L = p.L;
     const int nvalid = min(PN_R, B - r0);
 
@@ -760,6 +812,89 @@ __global__ __launch_bounds__(PN_T) void pn_backward_kernel(PnBwdP p) {
     }
 }
 
+// ---- weight gradients ---------------------------------------------------------------------------------------------------
+// dW_i[n][k] = sum_b dU_i[b][n] H_i[b][k] and db_i[n] = sum_b dU_i[b][n] for every block, and the same for the input
+// layer (dU := d loss / d h_0, H := x), in ONE launch behind the trunk's: workgroup (x, y, z) owns the 16 x 16 tile
+// (n-tile x, k-tile y) of layer z; its eight waves split the batch, each contracting its rows on
+// v_mfma_f32_16x16x4_f32 with both operands read straight from global memory (all loads of a batch of 16 MFMA steps in
+// flight together, branch-free), and the eight partial tiles are added through LDS in a fixed order.  The bias gradient
+// is the virtual column k = K of ones.  (smallnet.hip's column-owned form of this launch re-read the whole H_i per
+// workgroup through LDS: 13 us for the UCI net against ~6 here.)
+struct PnDwP {
+    const float* dU;   // [L][B][W]
+    const float* H;    // [L+1][B][W]
+    const float* G;    // [B][W]
+    const float* x;    // [B][din]
+    float *dW, *db;    // [L][W][W], [L][W]
+    float *dw_in, *db_in;
+    int B, W, L, din;
+};
+
+__global__ __launch_bounds__(PN_T) void pn_dw_kernel(PnDwP p) {
+    __shared__ __attribute__((aligned(16))) f32x4 s_acc[PN_T / 64][64];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int layer = blockIdx.z, n0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
+    const bool input = layer == p.L;
+    const int K = input ? p.din : p.W, ldh = K, B = p.B, W = p.W;
+    if (k0 > K) return;  // (uniform) this layer has no such tile
+    const float* A = input ? p.G : p.dU + (size_t)layer * B * W;  // [B][W]
+    const float* Hm = input ? p.x : p.H + (size_t)layer * B * W;  // [B][K]
+    // rows of this wave: a contiguous slice, a multiple of four rows long
+    const int per = (((B + 7) / 8) + 3) & ~3;
+    const int b0 = wv * per, b1 = min(B, b0 + per);
+    const int m = lane & 15, kq = lane >> 4;
+    const int n = n0 + m, kk = k0 + m;
+    const float amask = n < W ? 1.f : 0.f;
+    const float hmask = kk < K ? 1.f : 0.f, ones = kk == K ? 1.f : 0.f;
+    const unsigned acol = (unsigned)min(n, W - 1), hcol = (unsigned)min(kk, K - 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int CH = 16;
+    for (int s0 = b0; s0 < b1; s0 += 4 * CH) {
+        float av[CH], hv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int b = s0 + 4 * u + kq;
+            const unsigned bc = (unsigned)min(b, B - 1);
+            const float live = b < b1 ? 1.f : 0.f;
+            av[u] = A[bc * (unsigned)W + acol] * (amask * live);
+            hv[u] = Hm[bc * (unsigned)ldh + hcol] * hmask + ones;
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], hv[u], acc, 0, 0, 0);
+    }
+    s_acc[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0) {
+        f32x4 r = s_acc[0][lane];
+#pragma unroll
+        for (int w = 1; w < PN_T / 64; ++w) r += s_acc[w][lane];
+        float* dW = input ? p.dw_in : p.dW + (size_t)layer * W * W;
+        float* db = input ? p.db_in : p.db + (size_t)layer * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = n0 + 4 * kq + j;  // result layout: row 4 (lane >> 4) + j, column lane & 15
+            if (row < W) {
+                if (kk < K) dW[(size_t)row * K + kk] = r[j];
+                else if (kk == K) db[row] = r[j];
+            }
+        }
+    }
+}
+
+int pn_dw_all(const dun_fc_ctx* c, const float* dUall, hipStream_t s) {
+    PnDwP p;
+    memset(&p, 0, sizeof(p));
+    p.dU = dUall; p.H = c->H; p.G = c->G; p.x = c->x;
+    p.dW = c->g.w; p.db = c->g.b; p.dw_in = c->g.w_in; p.db_in = c->g.b_in;
+    p.B = c->B; p.W = c->W; p.L = c->L; p.din = c->din;
+    const int kmax = c->W > c->din ? c->W : c->din;
+    DUN_REQUIRE((long long)c->B * kmax < (1LL << 31), "dun_fc_backward: input too wide for the one-launch path");
+    hipLaunchKernelGGL(pn_dw_kernel, dim3((c->W + 15) / 16, kmax / 16 + 1, c->L + 1), dim3(PN_T), 0, s, p);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------------------
@@ -810,16 +945,35 @@ int pn_forward(const dun_fc_ctx* c, hipStream_t s) {
     return DUN_OK;
 }
 
-int pn_backward_trunk(const dun_fc_ctx* c, float* dUall, hipStream_t s) {
+int pn_backward_trunk(const dun_fc_ctx* c, float* dUall, bool head_from_forward, hipStream_t s) {
     PnBwdP p;
     memset(&p, 0, sizeof(p));
+    bool side = false;
+    if (head_from_forward) {
+        p.side.dwpart = c->obj_dwpart; p.side.dbpart = c->obj_dbpart; p.side.dw_out = c->g.w_out; p.side.db_out = c->g.b_out;
+        p.side.P = pn_workgroups(c->B); p.side.W = c->W;
+        side = true;
+    }
+    if (c->obj_fin_result && c->obj_fin_defer && c->obj_y && c->obj_partials) {
+        // the forward left the partial sums and deferred the depth-level finalisation to this launch
+        DUN_REQUIRE(c->obj_fin_logprior != nullptr && (c->obj_fin_objective == DUN_OBJ_MLL || c->obj_fin_q_logits != nullptr),
+                    "dun_fc_backward: deferred finalisation without logprior / q_logits");
+        DUN_REQUIRE(c->depth + 1 <= 512, "dun_fc_backward: deferred finalisation of more than 512 depths");
+        p.side.fin_result = c->obj_fin_result; p.side.fin_D = c->depth + 1; p.side.fin_nparts = pn_workgroups(c->B);
+        p.side.fin_objective = c->obj_fin_objective; p.side.fin_partials = c->obj_partials; p.side.fin_sums = c->obj_fin_sums;
+        p.side.fin_q_logits = c->obj_fin_q_logits; p.side.fin_logprior = c->obj_fin_logprior;
+        p.side.fin_prior_ll = c->obj_fin_prior_ll; p.side.fin_log_std = c->obj_log_std;
+        p.side.fin_N = c->obj_fin_N_train; p.side.fin_batch = c->obj_fin_batch; p.side.fin_beta = c->obj_fin_beta;
+        p.side.fin_eps = c->obj_fin_eps;
+        side = true;
+    }
     p.B = c->B; p.W = c->W; p.L = c->L; p.residual = c->residual; p.P = pn_workgroups(c->B);
     p.w = c->p.w; p.w_out = c->p.w_out; p.gamma = c->p.gamma;
     p.Z = c->Z; p.bn_mean = c->bn_mean; p.bn_rstd = c->bn_rstd;
     p.dact = c->dact; p.dU = dUall; p.G = c->G;
     p.dgamma = c->g.gamma; p.dbeta = c->g.beta;
     p.sync = c->sync; p.sync_bytes = (int)pn_sync_bytes(c->B, c->W);
-    const dim3 grid(p.P), block(PN_T);
+    const dim3 grid(p.P + (side ? 1 : 0)), block(PN_T);
 #define PN_BWD(N) case N: hipLaunchKernelGGL((pn_backward_kernel<N>), grid, block, 0, s, p); break;
     switch (pn_tiles(c->W)) { PN_BWD(2) PN_BWD(4) PN_BWD(7) PN_BWD(8) }
 #undef PN_BWD

@@ -21,7 +21,6 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "depth_finalize.h"
 
 namespace dun {
 
@@ -550,27 +549,7 @@ struct SnDwP {
     const float* H;   // [L(+1),B,W]
     float* dW;        // [L,W,W]
     float* db;        // [L,W]
-    int B, W, L;
-    // blockIdx.y == L (one-launch backward only): the input layer, dW_in = G^T x, db_in = sum_b G
-    const float* G;   // [B,W]
-    const float* x;   // [B,din]
-    float* dw_in;     // [W,din]
-    float* db_in;     // [W]
-    int din, vec_in;
-    // blockIdx.y == L + 1 (one-launch backward, head gradients accumulated by the forward): dw_out, db_out from the
-    // per-workgroup partial sums [P][W], [P]
-    const float* dwpart;
-    const float* dbpart;
-    float* dw_out;
-    float* db_out;
-    int P;
-    // blockIdx.y == y_fin (>= 0: deferred finalisation of the objective, workgroup x == 0 only): dun_depth_finalize_partials
-    int y_fin, fin_D, fin_nparts, fin_objective;
-    const double* fin_partials;
-    double* fin_sums;
-    const float *fin_q_logits, *fin_logprior, *fin_prior_ll, *fin_log_std;
-    double fin_N, fin_batch, fin_beta, fin_eps;
-    float* fin_result;
+    int B, W;
 };
 __global__ __launch_bounds__(SN_T) void sn_dw_batched_kernel(SnDwP p) {
     extern __shared__ __attribute__((aligned(16))) char sn_smem[];
@@ -578,52 +557,10 @@ __global__ __launch_bounds__(SN_T) void sn_dw_batched_kernel(SnDwP p) {
     float* obuf = reinterpret_cast<float*>(sn_smem + SN_OFF_OBUF);
     const int c0 = blockIdx.x * SN_NC, i = blockIdx.y;
     const size_t plane = (size_t)p.B * p.W;
-    if (i == p.y_fin) {  // same arithmetic and summation order as depth_reduce_finalize_kernel (elbo.hip)
-        if (blockIdx.x != 0) return;
-        double* sh_sums = reinterpret_cast<double*>(sn_smem);
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        for (int d = wv; d < p.fin_D; d += SN_WAVES) {
-            double a = 0.0;
-            for (int k = lane; k < p.fin_nparts; k += 64) a += p.fin_partials[(size_t)d * p.fin_nparts + k];
-            a = wave_sum(a);
-            if (lane == 0) {
-                sh_sums[d] = a;
-                if (p.fin_sums) p.fin_sums[d] = a;
-            }
-        }
-        __syncthreads();
-        if (wv == 0)
-            depth_finalize_body(sh_sums, 1, p.fin_q_logits, p.fin_logprior, p.fin_prior_ll, p.fin_log_std, p.fin_D, p.fin_N,
-                                p.fin_batch, p.fin_beta, p.fin_eps, p.fin_objective, p.fin_result);
-        return;
-    }
-    if (i == p.L + 1 && p.dwpart == nullptr) return;
-    if (i == p.L + 1) {  // fp64, fixed order: a wavefront per column, lanes stride over the partials
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (wv < SN_NC) {
-            double a = 0.0;
-            for (int q = lane; q < p.P; q += 64) a += (double)p.dwpart[(size_t)q * p.W + c0 + wv];
-            a = wave_sum(a);
-            if (lane == 0) p.dw_out[c0 + wv] = (float)a;
-        } else if (wv == SN_NC && blockIdx.x == 0) {
-            double a = 0.0;
-            for (int q = lane; q < p.P; q += 64) a += (double)p.dbpart[q];
-            a = wave_sum(a);
-            if (lane == 0) p.db_out[0] = (float)a;
-        }
-        return;
-    }
-    const float* dU = (i == p.L ? p.G : p.dU + (size_t)i * plane) + c0;
+    const float* dU = p.dU + (size_t)i * plane + c0;
     for (int r = threadIdx.x; r < p.B; r += SN_T)
         *reinterpret_cast<f32x4*>(obuf + 4 * r) = *reinterpret_cast<const f32x4*>(dU + (size_t)r * p.W);
     __syncthreads();
-    if (i == p.L) {
-        if (p.vec_in)
-            sn_dw_phase<4>(obuf, rbuf, p.x, p.din, p.din, p.B, p.dw_in, p.db_in, c0);
-        else
-            sn_dw_phase<1>(obuf, rbuf, p.x, p.din, p.din, p.B, p.dw_in, p.db_in, c0);
-        return;
-    }
     sn_dw_phase<4>(obuf, rbuf, p.H + (size_t)i * plane, p.W, p.W, p.B, p.dW + (size_t)i * p.W * p.W, p.db + (size_t)i * p.W, c0);
 }
 
@@ -768,52 +705,13 @@ int sn_backward_blocks(const dun_fc_ctx* c, float* dUall, hipStream_t s) {
     }
     if (L > 0) {
         SnDwP q;
-        memset(&q, 0, sizeof(q));
-        q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W; q.L = L; q.y_fin = -1;
+        q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W;
         const size_t lds = sn_lds(B);
         int rc = sn_allow_lds(sn_dw_batched_kernel, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(sn_dw_batched_kernel, dim3(W / SN_NC, L), dim3(SN_T), lds, s, q);
         DUN_LAUNCH_CHECK();
     }
-    return DUN_OK;
-}
-
-// Weight gradients of the one-launch backward (persist.hip): every block, the input layer and -- when the forward
-// accumulated them -- the head's partial sums, in ONE launch of grid (W/4, L + 1 or L + 2).
-int sn_dw_all(const dun_fc_ctx* c, const float* dUall, bool head_from_forward, hipStream_t s) {
-    const int W = c->W, B = c->B, L = c->L;
-    SnDwP q;
-    memset(&q, 0, sizeof(q));
-    q.dU = dUall; q.H = c->H; q.dW = c->g.w; q.db = c->g.b; q.B = B; q.W = W; q.L = L;
-    q.G = c->G; q.x = c->x; q.dw_in = c->g.w_in; q.db_in = c->g.b_in; q.din = c->din;
-    q.vec_in = ((c->din & 3) == 0 && sn_al16(c->x) && sn_al16(c->g.w_in)) ? 1 : 0;
-    int ny = L + 1;
-    q.y_fin = -1;
-    if (head_from_forward) {
-        q.dwpart = c->obj_dwpart; q.dbpart = c->obj_dbpart; q.dw_out = c->g.w_out; q.db_out = c->g.b_out;
-        q.P = (B + 15) / 16;
-        ny = L + 2;
-    }
-    if (c->obj_fin_result && c->obj_fin_defer && c->obj_y && c->obj_partials) {
-        // the forward left the partial sums and deferred the depth-level finalisation to this launch
-        DUN_REQUIRE(c->obj_fin_logprior != nullptr && (c->obj_fin_objective == DUN_OBJ_MLL || c->obj_fin_q_logits != nullptr),
-                    "dun_fc_backward: deferred finalisation without logprior / q_logits");
-        DUN_REQUIRE(c->depth + 1 <= 512, "dun_fc_backward: deferred finalisation of more than 512 depths");
-        q.y_fin = L + 2;  // (row L + 1 stays the head's, run or not: a workgroup of an unused row returns at once)
-        ny = L + 3;
-        q.fin_D = c->depth + 1; q.fin_nparts = (B + 15) / 16; q.fin_objective = c->obj_fin_objective;
-        q.fin_partials = c->obj_partials; q.fin_sums = c->obj_fin_sums;
-        q.fin_q_logits = c->obj_fin_q_logits; q.fin_logprior = c->obj_fin_logprior; q.fin_prior_ll = c->obj_fin_prior_ll;
-        q.fin_log_std = c->obj_log_std;
-        q.fin_N = c->obj_fin_N_train; q.fin_batch = c->obj_fin_batch; q.fin_beta = c->obj_fin_beta; q.fin_eps = c->obj_fin_eps;
-        q.fin_result = c->obj_fin_result;
-    }
-    const size_t lds = sn_lds(B);
-    int rc = sn_allow_lds(sn_dw_batched_kernel, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(sn_dw_batched_kernel, dim3(W / SN_NC, ny), dim3(SN_T), lds, s, q);
-    DUN_LAUNCH_CHECK();
     return DUN_OK;
 }
 

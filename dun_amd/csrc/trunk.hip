@@ -28,11 +28,11 @@ size_t sn_extra_ws_floats(int B, int W, int L);
 bool sn_eligible(const dun_fc_ctx* c, bool backward);
 int sn_forward_block(const dun_fc_ctx* c, int i, hipStream_t s);
 int sn_backward_blocks(const dun_fc_ctx* c, float* dUall, hipStream_t s);
-int sn_dw_all(const dun_fc_ctx* c, const float* dUall, bool head_from_forward, hipStream_t s);
+int pn_dw_all(const dun_fc_ctx* c, const float* dUall, hipStream_t s);
 // persist.hip: the whole forward / the whole backward of a small net in ONE launch each (row-owning workgroups)
 bool pn_eligible(const dun_fc_ctx* c);
 int pn_forward(const dun_fc_ctx* c, hipStream_t s);
-int pn_backward_trunk(const dun_fc_ctx* c, float* dUall, hipStream_t s);
+int pn_backward_trunk(const dun_fc_ctx* c, float* dUall, bool head_from_forward, hipStream_t s);
 
 // rows per column-reduction partial: 128, or 32 for small batches (four times the workgroups, a quarter of the serial
 // row loop: the UCI-sized nets are latency bound)
@@ -959,11 +959,10 @@ static int bwd_begin(const dun_fc_ctx* c, hipStream_t s) {
 
 // The column sums sum_b g and sum_b g*xhat of block i are taken in the epilogue of the dX GEMM of block i+1, while the
 // tile of g it has just computed is in registers (one read of Z_i instead of a pass over g and Z_i): every block but the
-// deepest, whose incoming gradient does not come out of a GEMM.  DUN_BWD_STATS_IN_GEMM=0 keeps the separate pass (A/B).
-static const bool g_stats_in_gemm = !(getenv("DUN_BWD_STATS_IN_GEMM") && getenv("DUN_BWD_STATS_IN_GEMM")[0] == '0');
+// deepest, whose incoming gradient does not come out of a GEMM.
 // (one head output only: the statistics epilogue is compiled without the general rank-O update, whose per-row address
 // registers made it spill its Z tile one HBM round trip at a time)
-static inline bool stats_from_gemm(const dun_fc_ctx* c, int i) { return g_stats_in_gemm && c->O == 1 && i < c->L - 1; }
+static inline bool stats_from_gemm(const dun_fc_ctx* c, int i) { return c->O == 1 && i < c->L - 1; }
 
 static int bwd_block_reduce(const dun_fc_ctx* c, int i, hipStream_t s) {
     const int W = c->W, B = c->B;
@@ -1005,9 +1004,7 @@ static int bwd_block_du(const dun_fc_ctx* c, int i, double global_batch, hipStre
     const float* mean = c->bn_mean + (size_t)i * W;
     const float* rstd = c->bn_rstd + (size_t)i * W;
     const float* gamma = c->p.gamma + (size_t)i * W;
-    // A/B hook: DUN_BWD_ROWS=0 keeps the column-owned kernel at every size
-    static const bool rows_ok = !(getenv("DUN_BWD_ROWS") && getenv("DUN_BWD_ROWS")[0] == '0');
-    if (rows_ok && nt && W % 256 == 0 && W <= 2048 && vec4_ok(W, c->G, Z, c->dU) && aligned16(c->ws)) {
+    if (nt && W % 256 == 0 && W <= 2048 && vec4_ok(W, c->G, Z, c->dU) && aligned16(c->ws)) {
         // P workgroups of four wavefronts, slab_rows/4 rows per wavefront; partials [P][W] as below
 #define BBR(N) case N: hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<N, true>), dim3(P), dim3(256), 0, s, c->G, Z, mean, rstd, \
                                           gamma, c->bn_sums, global_batch, B, c->dU, c->ws); break;
@@ -1047,10 +1044,9 @@ static int bwd_block_dw(const dun_fc_ctx* c, int i, hipStream_t s) {
 // the OUTPUT index of W_i[n_out][k_in], so W_i as stored is the N-contiguous operand; with both operands K-contiguous
 // the same kernel runs at the forward GEMM's rate (measured box to box 25 ... 150 us per launch faster at the wide
 // configuration's shape), for one 2 x L x W^2 x 4-byte transposition per backward (0.3 ms at 50 x 2048^2) and one more
-// copy of the block weights in the workspace.  DUN_DX_TRANSPOSED=0 keeps the weights as stored (A/B).
-static const bool g_dx_transposed = !(getenv("DUN_DX_TRANSPOSED") && getenv("DUN_DX_TRANSPOSED")[0] == '0');
+// copy of the block weights in the workspace.
 static inline bool dx_transposed(int B, int W, int L) {
-    return g_dx_transposed && L > 0 && W % 128 == 0 && B % 128 == 0 && (long long)ceil_div(B, 128) * (W / 128) >= 128;
+    return L > 0 && W % 128 == 0 && B % 128 == 0 && (long long)ceil_div(B, 128) * (W / 128) >= 128;
 }
 static size_t base_workspace_floats(int B, int W, int O, int L);
 static inline float* wT_base(const dun_fc_ctx* c) { return c->ws + base_workspace_floats(c->B, c->W, c->O, c->L); }
@@ -1248,8 +1244,8 @@ extern "C" int dun_fc_backward(const dun_fc_ctx* c, dun_stream_t stream) {
         else if ((rc = head_backward(c->H, c->p.w_out, c->dact, (c->depth + 1) * c->B, c->W, c->O, c->g.w_out, c->g.b_out,
                                      nullptr, c->ws, c->ws_floats, STREAM)))
             return rc;
-        if ((rc = pn_backward_trunk(c, dUall, STREAM))) return rc;
-        return sn_dw_all(c, dUall, from_fwd, STREAM);
+        if ((rc = pn_backward_trunk(c, dUall, from_fwd, STREAM))) return rc;
+        return pn_dw_all(c, dUall, STREAM);
     }
     if (sn_eligible(c, true)) {  // small net: head gradients, then one column-owned launch per block + input layer
         const int rows = (c->depth + 1) * c->B;
@@ -1376,6 +1372,38 @@ __global__ __launch_bounds__(256) void copy_pair_kernel(char* d0, const char* s0
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = s[i];
 }
 }  // namespace dun
+
+namespace dun {
+__global__ __launch_bounds__(256) void copy_pair_indirect_kernel(char* d0, size_t n0, char* d1, size_t n1,
+                                                                 const char* const* table) {
+    char* d = blockIdx.y == 0 ? d0 : d1;
+    const char* s = table[blockIdx.y];
+    const size_t n = blockIdx.y == 0 ? n0 : n1;
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+        const size_t n16 = n / 16;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+            reinterpret_cast<f32x4*>(d)[i] = reinterpret_cast<const f32x4*>(s)[i];
+        for (size_t i = n16 * 16 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = s[i];
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = s[i];
+}
+}  // namespace dun
+
+extern "C" int dun_copy_pair_indirect(void* dst0, size_t bytes0, void* dst1, size_t bytes1, const void* const* src_table,
+                                      dun_stream_t stream) {
+    DUN_REQUIRE(src_table != nullptr && (bytes0 == 0 || dst0) && (bytes1 == 0 || dst1), "dun_copy_pair_indirect: null pointer");
+    const size_t nmax = bytes0 > bytes1 ? bytes0 : bytes1;
+    if (nmax == 0) return DUN_OK;
+    size_t blocks = (nmax / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_pair_indirect_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, STREAM, static_cast<char*>(dst0),
+                       bytes0, static_cast<char*>(dst1), bytes1, reinterpret_cast<const char* const*>(src_table));
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
 
 extern "C" int dun_copy_pair(void* dst0, const void* src0, size_t bytes0, void* dst1, const void* src1, size_t bytes1,
                              dun_stream_t stream) {

@@ -6,7 +6,6 @@ Everything the rest of the package computes on the hot path goes through the obj
 stand-in (tests/cpu_backend.py); nothing in the package itself ever installs another backend.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -126,8 +125,7 @@ class FcBuffers(object):
             if not L.lib().dun_fc_objective_in_forward(C.byref(c)):
                 c.obj_fin_result = c.obj_fin_sums = c.obj_fin_q_logits = c.obj_fin_logprior = None
                 spec.res = spec.sums = None
-        if spec.dact is not None and self.train and os.environ.get("DUN_HEAD_DW_IN_FORWARD", "1") != "0" \
-                and L.lib().dun_fc_head_grads_in_forward(C.byref(c)):
+        if spec.dact is not None and self.train and L.lib().dun_fc_head_grads_in_forward(C.byref(c)):
             # the head's weight / bias gradient is accumulated by the forward's head kernels (per-workgroup partials,
             # kept with the buffers: [D, nparts, W] floats, 214 MB at the wide configuration)
             if self._dwpart is None:
@@ -281,7 +279,13 @@ class HipBackend(object):
         mean = torch.empty(n, device=dev, dtype=torch.float32)
         std = torch.empty(n, device=dev, dtype=torch.float32)
         q = torch.empty(D, device=dev, dtype=torch.float32)
-        m = out[1:]
+        m = out[1:3]
+        if out.numel() > 3:  # out[3]: completion word (pinned host memory a captured step polls instead of synchronising)
+            L.check(lib.dun_predict_gauss_step_signal(L.f32(act), L.f32(q_logits), 1, D, n, L.f32(mean), L.f32(std), L.f32(y),
+                                                      L.f32(log_std), L.out_ptr(m), L.f32(q), L.f32(objective),
+                                                      L.out_ptr(out), L.out_ptr(out[3:4]), L.stream_ptr(dev)),
+                    "dun_predict_gauss_step_signal")
+            return q
         L.check(lib.dun_predict_gauss_step(L.f32(act), L.f32(q_logits), 1, D, n, L.f32(mean), L.f32(std), L.f32(y),
                                            L.f32(log_std), L.out_ptr(m), L.out_ptr(m), L.f32(q), L.f32(objective),
                                            L.out_ptr(out), L.stream_ptr(dev)), "dun_predict_gauss_step")
@@ -370,6 +374,13 @@ class HipBackend(object):
         L.check(L.lib().dun_copy_pair(L.ptr(dst0), L.ptr(src0), dst0.numel() * dst0.element_size(), L.ptr(dst1),
                                       L.ptr(src1), dst1.numel() * dst1.element_size(), L.stream_ptr(dst0.device)),
                 "dun_copy_pair")
+
+    def copy_pair_indirect(self, dst0, dst1, table):
+        """dst0 <- *table[0], dst1 <- *table[1]: the source addresses (int64 [2], pinned host or device memory) are read
+        when the launch runs, so a captured step keeps its input copies inside the graph."""
+        L.check(L.lib().dun_copy_pair_indirect(L.ptr(dst0), dst0.numel() * dst0.element_size(), L.ptr(dst1),
+                                               dst1.numel() * dst1.element_size(), L.out_ptr(table),
+                                               L.stream_ptr(dst0.device)), "dun_copy_pair_indirect")
 
     def sgd_step_multi(self, triples, lr, momentum, weight_decay):
         """The same update over several (param, grad, momentum buffer) triples, DUN_SGD_MAX_SEGMENTS per launch."""

@@ -114,12 +114,14 @@ class DUN(BaseNet):
             if step is not None and self.regression and self._dist is None and objective is not None:
                 # (a captured step hands over pinned host memory: the kernel's three doubles go home without a copy node)
                 pinned = self.__dict__.get("_metrics_out")
-                out = pinned[:3] if pinned is not None else torch.empty(3, device=act.device, dtype=torch.float64)
+                out = pinned[:4] if pinned is not None else torch.empty(3, device=act.device, dtype=torch.float64)
                 q = step(act, q_logits.detach(), y.to(torch.float32).contiguous(), self.f_neg_loglike.log_std.detach(),
                          objective.detach().reshape(1), out)
                 if q is not None:
                     self.prob_model.current_posterior = q
-                    return out, act[0].numel()
+                    if pinned is not None:
+                        self._metrics_signalled = True  # out[3] is the completion word of this (captured) step
+                    return out[:3], act[0].numel()
             self.prob_model.current_posterior = self.prob_model.get_q_probs().detach()
         post = self.prob_model.current_posterior
         # [objective,] nll_sum, err_sum[, bad_labels] in ONE fp64 tensor: the kernel writes its sums straight into it
@@ -209,17 +211,25 @@ class DUN(BaseNet):
             return self._metrics_host(*step_fn(x, y))
         states[key] = states.pop(key)  # most recently used last
         self._graph_state = st
+        x, y = x.contiguous(), y.contiguous()
         if st["graph"] is None:
-            # second step with the same configuration: capture.  The returned scalars leave through a device -> pinned
-            # host copy INSIDE the graph, so a replayed step is: one input-copy launch, one graph launch, one stream wait
-            sx = x.contiguous().clone()
-            sy = y.contiguous().clone()
+            # Second step with the same configuration: capture.  Host traffic of a replayed step is kept to memory
+            # writes: the graph's first node copies x and y from wherever a two-pointer table in pinned memory says (the
+            # host rewrites the table, no copy launch), and the returned scalars are written by the last kernel straight
+            # into pinned memory together with a completion word the host polls (no stream synchronisation); metric
+            # kernels that cannot do that leave through a device -> pinned copy node and a stream wait.
+            be = kernels.backend()
+            sx, sy = x.clone(), y.clone()
             graph = torch.cuda.CUDAGraph()
-            pinned = torch.empty(8, dtype=torch.float64, pin_memory=True)  # (allocated outside the capture)
+            pinned = torch.zeros(8, dtype=torch.float64, pin_memory=True)  # (allocated outside the capture)
+            table = torch.zeros(2, dtype=torch.int64, pin_memory=True)
+            indirect = getattr(be, "copy_pair_indirect", None)
             torch.cuda.synchronize()
             self._metrics_out = pinned
             try:
                 with torch.cuda.graph(graph):
+                    if indirect is not None:
+                        indirect(sx, sy, table)
                     m, n = step_fn(sx, sy)
                     host = m
                     if m.is_cuda:  # (the metric kernels of this configuration write device memory)
@@ -230,17 +240,28 @@ class DUN(BaseNet):
             # the graph holds raw pointers into the trunk's activation buffers: keep them alive as long as the graph
             # (the model's buffer cache evicts on its own schedule)
             keep = list(getattr(self.model, "_fc_cache", {}).values())
-            st.update(graph=graph, x=sx, y=sy, m=m, n=n, host=host, posterior=self.prob_model.current_posterior, keep=keep)
+            st.update(graph=graph, x=sx, y=sy, m=m, n=n, host=host, posterior=self.prob_model.current_posterior, keep=keep,
+                      table=table.numpy() if indirect is not None else None,
+                      poll=pinned.numpy() if (not m.is_cuda and self.__dict__.pop("_metrics_signalled", False)) else None)
+        tbl = st["table"]
+        if tbl is not None:
+            tbl[0], tbl[1] = x.data_ptr(), y.data_ptr()  # (x and y stay alive until this call has its results)
         else:
-            copy_pair = getattr(kernels.backend(), "copy_pair", None)
-            if copy_pair is not None and x.is_contiguous() and y.is_contiguous():
-                copy_pair(st["x"], x, st["y"], y)
-            else:
-                st["x"].copy_(x, non_blocking=True)
-                st["y"].copy_(y, non_blocking=True)
+            st["x"].copy_(x, non_blocking=True)
+            st["y"].copy_(y, non_blocking=True)
+        poll = st["poll"]
+        if poll is not None:
+            poll[3] = 0.0
         st["graph"].replay()
         self.prob_model.current_posterior = st["posterior"]
-        torch.cuda.current_stream().synchronize()
+        if poll is not None:
+            for _ in range(200000):  # the step's last kernel stores 1.0 behind its scalars
+                if poll[3] == 1.0:
+                    break
+            else:
+                torch.cuda.current_stream().synchronize()
+        else:
+            torch.cuda.current_stream().synchronize()
         return self._metrics_host(st["host"], st["n"])
 
     def _prior_loglikes(self):

@@ -68,7 +68,7 @@ class BaseNet(object):
 
     def __getstate__(self):
         st = self.__dict__.copy()
-        for k in ("_graph_state", "_graph_states", "_metrics_out"):  # captured hipGraphs do not pickle
+        for k in ("_graph_state", "_graph_states", "_metrics_out", "_metrics_signalled"):  # captured hipGraphs do not pickle
             st.pop(k, None)
         st["_dist"] = None
         return st

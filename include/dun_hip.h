@@ -136,6 +136,13 @@ int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mea
 int dun_predict_gauss_step(const float* act, const float* q, int q_is_logits, int D, int n, float* mean, float* std,
                            const float* y, const float* log_std, double* partials, double* metrics, float* q_out,
                            const float* objective_src, double* objective_dst, dun_stream_t stream);
+/* The same with a completion word: metrics / objective_dst / done may be pinned HOST memory (device-mapped), and the
+ * thread that wrote the scalars stores 1.0 to done[0] behind a system-scope fence -- a host that zeroed the word before
+ * enqueueing can read the step's scalars as soon as it sees the 1.0, without a stream synchronisation.  Only where the
+ * predictor is one workgroup (dun_predict_num_partials(n, 1) == 1; DUN_ERR_UNSUPPORTED otherwise). */
+int dun_predict_gauss_step_signal(const float* act, const float* q, int q_is_logits, int D, int n, float* mean, float* std,
+                                  const float* y, const float* log_std, double* metrics, float* q_out,
+                                  const float* objective_src, double* objective_dst, double* done, dun_stream_t stream);
 /* Softmax: act [D,B,C] -> probs [B,C] = sum_d q_d softmax(act[d,b,:]).
  *   metrics (nullable, double [3]; needs y int64 [B]): sum_b -log probs[b,y_b], count(argmax != y), count of labels
  *   outside [0,C) other than -100.  y == -100 adds 0 to the first (nn.NLLLoss's ignore_index,
@@ -183,6 +190,18 @@ typedef struct dun_gemm_desc {
     int ldz;
 } dun_gemm_desc;
 int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream);
+/* Measurement hook (no counterpart in the reference; bench.py's in-step roofline): between _begin and _end every
+ * dun_gemm_f32 launch -- those inside dun_fc_forward / dun_fc_backward included -- is bracketed by two HIP events on its
+ * stream.  _end waits for them and fills up to `cap` records in launch order, returning how many.  `epilogue` bits:
+ * 1 bias, 2 ReLU, 4 residual, 8 rank-O update, 16 colstats, 32 BatchNorm-backward statistics; `kernel`: 0 register-staged,
+ * 1 LDS-DMA 128x128 tiles, 2 LDS-DMA 128x256 tiles; `ms` includes the split-K sum where ksplit > 1.  HOST calls; one
+ * window at a time. */
+typedef struct dun_gemm_profile_rec {
+    int M, N, K, a_kcontig, b_kcontig, epilogue, kernel, ksplit;
+    float ms;
+} dun_gemm_profile_rec;
+int dun_gemm_profile_begin(int max_launches);
+int dun_gemm_profile_end(dun_gemm_profile_rec* out /* host */, int cap);
 /* Row tiles the kernel uses for an M x N problem (128-row tiles; 64-row tiles when the problem is too small to fill
  * the chip with 128x128 tiles).  No reference counterpart: sizing helper for `colstats`. */
 int dun_gemm_colstat_tiles(int M, int N);
@@ -370,6 +389,10 @@ int dun_sgd_step_multi(const dun_sgd_segment* segments /* host array */, int nse
  * x and y of src/DUN/training_wrappers.py:215; host glue, no arithmetic).  Byte counts; any alignment. */
 int dun_copy_pair(void* dst0, const void* src0, size_t bytes0, void* dst1, const void* src1, size_t bytes1,
                   dun_stream_t stream);
+/* The same with the two SOURCE addresses read at run time from src_table[0..1] (device or pinned host memory): a captured
+ * step keeps this launch inside its graph and the host only rewrites two pointers before each replay. */
+int dun_copy_pair_indirect(void* dst0, size_t bytes0, void* dst1, size_t bytes1, const void* const* src_table,
+                           dun_stream_t stream);
 
 #ifdef __cplusplus
 }
