@@ -44,7 +44,9 @@ class GemmDesc(C.Structure):
                 ("U", C.c_void_p), ("V", C.c_void_p), ("O", C.c_int), ("ldv", C.c_int),
                 ("colstats", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_floats", C.c_size_t),
                 ("bnz", C.c_void_p), ("bn_mean", C.c_void_p), ("bn_rstd", C.c_void_p), ("bnstats", C.c_void_p),
-                ("ldz", C.c_int)]
+                ("ldz", C.c_int),
+                ("ev_mean", C.c_void_p), ("ev_scale", C.c_void_p), ("ev_shift", C.c_void_p), ("ev_head_w", C.c_void_p),
+                ("ev_head_part", C.c_void_p)]
 
 
 class GemmProfileRec(C.Structure):

@@ -55,6 +55,12 @@ struct GemmP {
     float* part;  // [ksplit][M][N]
     int rinit;    // LDS-DMA kernel: accumulators start from R (loaded under the pipeline prologue), not added at the end
     int wide;     // 128 x 256 tiles (gemm_f32_wide_kernel): gridN counts 256-column tiles
+    // inference epilogue (dun_gemm_desc::ev_*): eval-mode BatchNorm + residual + the head's partial row-dot
+    const float* ev_mean;
+    const float* ev_scale;
+    const float* ev_shift;
+    const float* ev_hw;
+    float* ev_hpart;
 };
 
 // ---- global -> register staging of one operand tile: 4 x float4 per thread ----
@@ -354,6 +360,78 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmP& p, f32x16 (&acc)
                 p.colstats[(size_t)bm * p.N + col] = t1;
                 p.colstats[(size_t)(p.gridM + bm) * p.N + col] = t2;
             }
+        }
+    }
+}
+
+// Inference epilogue of a trunk block (whole 128 x 128 tiles): with BatchNorm in eval mode the block is a per-column
+// affine map of ReLU(Linear), so  C = [R +] (max(acc + bias, 0) - mean) * scale + shift  leaves the GEMM as the next
+// hidden state -- no ReLU(Linear) tensor is written and no normalisation pass re-reads it -- and the shared head's
+// row-dot over this tile's 128 columns, hpart[bn][row] = sum_n C[row][n] hw[n], is taken while the tile is in
+// registers ((z - mean) first, then scale: the arithmetic of bn_apply_kernel, see there).  The 32 row sums of a lane are
+// reduced over the 32 lanes of its half on the DPP path, the two wave columns are added through LDS in a fixed order.
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_eval(const GemmP& p, f32x16 (&acc)[MI][NI], float* smem, int m0, int n0, int bn,
+                                                   int tid, int wr, int wc, int li, int h) {
+    constexpr int WTN = 32 * NI;           // columns of a wave's sub-tile: 64 (two wave columns per 128-column partial) or 128
+    constexpr int NC = NI > 2 ? 2 : NI;    // accumulator columns whose residual values are gathered at a time
+    const TileIO<true, MI, NI> Cio(p.C, p.ldc, p, m0, n0, wr, wc, li, h);
+    const TileIO<true, MI, NI> Rio(p.R != nullptr ? p.R : p.C, p.R != nullptr ? p.ldr : p.ldc, p, m0, n0, wr, wc, li, h);
+    float bv[NI], mu[NI], sc[NI], sh[NI], hw[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = n0 + wc * WTN + ni * 32 + li;
+        bv[ni] = p.bias[col]; mu[ni] = p.ev_mean[col]; sc[ni] = p.ev_scale[col]; sh[ni] = p.ev_shift[col];
+        hw[ni] = p.ev_hw != nullptr ? p.ev_hw[col] : 0.f;
+    }
+    float* hp_s = smem;  // [2 wave columns][128 rows]; all waves are past the last barrier: LDS is free
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        float hp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hp[r] = 0.f;
+#pragma unroll
+        for (int n0c = 0; n0c < NI; n0c += NC) {
+            float aux[NC][16];
+            if (p.R != nullptr) {
+#pragma unroll
+                for (int nc = 0; nc < NC; ++nc)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) aux[nc][r] = Rio.load(mi, n0c + nc, r);
+            }
+#pragma unroll
+            for (int nc = 0; nc < NC; ++nc) {
+                const int ni = n0c + nc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = fmaxf(acc[mi][ni][r] + bv[ni], 0.f);
+                    v = (v - mu[ni]) * sc[ni] + sh[ni];
+                    if (p.R != nullptr) v = aux[nc][r] + v;
+                    Cio.store(mi, ni, r, v);
+                    hp[r] += v * hw[ni];
+                }
+            }
+            if (NI > 2) __builtin_amdgcn_sched_barrier(0);  // (128 accumulators: keep one chunk's temporaries alive at a time)
+        }
+        if (p.ev_hpart != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = hp[r];
+                x += dpp_move<DPP_QUAD_XOR1>(x);
+                x += dpp_move<DPP_QUAD_XOR2>(x);
+                x += dpp_move<DPP_ROW_HALF_MIRROR>(x);
+                x += dpp_move<DPP_ROW_MIRROR>(x);
+                x += __shfl_xor(x, 16, 64);  // the other 16-lane row of this half
+                if (li == 0) hp_s[wc * 128 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = x;
+            }
+        }
+    }
+    if (p.ev_hpart != nullptr) {
+        __syncthreads();
+        if (NI == 2) {  // 128-column tile: the two wave columns are one partial
+            if (tid < 128) p.ev_hpart[(size_t)bn * p.M + m0 + tid] = hp_s[tid] + hp_s[128 + tid];
+        } else {        // 256-column tile: a partial per wave column, the [N/128][M] layout all the same
+            p.ev_hpart[(size_t)(bn * 2 + (tid >> 7)) * p.M + m0 + (tid & 127)] = hp_s[tid];
         }
     }
 }
@@ -677,6 +755,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
         q.ldc = p.N;
         q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr; q.bnz = nullptr;
         gemm_epilogue<true, 2>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    } else if (p.ev_scale != nullptr) {
+        gemm_epilogue_eval<2, 2>(p, acc, smem, m0, n0, bn, tid, wr, wc, li, h);
     } else {
         gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
     }
@@ -866,7 +946,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[mi], vb[ni], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();  // the epilogue reuses the LDS for the column statistics
-    gemm_epilogue<true, 2, 4, true>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    if (p.ev_scale != nullptr)
+        gemm_epilogue_eval<2, 4>(p, acc, smem, m0, n0, bn, tid, wr, wc, li, h);
+    else
+        gemm_epilogue<true, 2, 4, true>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
 }
 
 // (explicit instantiations: the host pass emitted the launch stub of <true, true> only)
@@ -984,6 +1067,7 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     const int tile = small ? 64 : BM;
     p.gridM = ceil_div(d->M, tile);
     p.gridN = ceil_div(d->N, tile);
+    p.ev_mean = d->ev_mean; p.ev_scale = d->ev_scale; p.ev_shift = d->ev_shift; p.ev_hw = d->ev_head_w; p.ev_hpart = d->ev_head_part;
     DUN_REQUIRE((long long)p.gridM * p.gridN < (1ll << 31), "dun_gemm_f32: grid too large");
     // float4 staging needs 16-byte aligned rows on both operands; anything else takes the scalar loads
     const bool va = aligned16(d->A) && d->lda % 4 == 0 && (d->a_kcontig ? d->K % 4 == 0 : d->M % 4 == 0);
@@ -1034,16 +1118,25 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
         }
         p.rinit = can_seed ? 1 : 0;
     }
-    {
-        // 128 x 256 tiles where they fill the chip without split-K (the trunk's forward and dX GEMMs): the per-tile
-        // prologue / store bubble is paid once per twice the work.
-        if (dma && p.ksplit == 1 && d->N % WBN == 0 &&
-            (long long)p.gridM * (d->N / WBN) >= 512 && d->K >= 64 && (!d->R || p.rinit) &&
-            (!d->U || (d->O == 1 && !d->bias && !d->relu)) &&
-            (d->a_kcontig || !d->b_kcontig)) {  // (the <M-contiguous, K-contiguous> instantiation spills: none of the trunk's GEMMs)
-            p.wide = 1;
-            p.gridN = d->N / WBN;
+    if (d->ev_scale != nullptr) {
+        // the inference epilogue exists in the two LDS-DMA kernels (whole tiles, no split-K)
+        if (!(dma && p.ksplit == 1 && d->bias && d->relu && d->ev_mean && d->ev_shift && !d->colstats && !d->bnz && !d->U &&
+              (d->ev_head_w == nullptr) == (d->ev_head_part == nullptr))) {
+            set_error("dun_gemm_f32: the inference epilogue needs whole 128x128 tiles (>= 128 of them), 16-byte aligned operands, "
+                      "bias + ReLU, ev_mean / ev_scale / ev_shift, and no statistics / rank update");
+            return DUN_ERR_UNSUPPORTED;
         }
+        p.rinit = 0;
+    }
+    // 128 x 256 tiles where they fill the chip without split-K (the trunk's forward and dX GEMMs): the per-tile
+    // prologue / store bubble is paid once per twice the work.  (A residual must seed the accumulators there, or be added
+    // by the inference epilogue, which gathers it chunk by chunk.)
+    if (dma && p.ksplit == 1 && d->N % WBN == 0 &&
+        (long long)p.gridM * (d->N / WBN) >= 512 && d->K >= 64 && (!d->R || p.rinit || d->ev_scale) &&
+        (!d->U || (d->O == 1 && !d->bias && !d->relu)) &&
+        (d->a_kcontig || !d->b_kcontig)) {  // (the <M-contiguous, K-contiguous> instantiation spills: none of the trunk's GEMMs)
+        p.wide = 1;
+        p.gridN = d->N / WBN;
     }
     GemmProfSlot* slot = gemm_profile_open(d, p.wide ? 2 : (dma ? 1 : 0), p.ksplit, s);
     int rc;

@@ -903,6 +903,66 @@ static int block_norm(const dun_fc_ctx* c, int i, double global_batch, hipStream
     return DUN_OK;
 }
 
+// ---- inference trunk: BatchNorm(eval) + residual + head partials inside the block GEMM's epilogue ---------------------
+// scale[i][n] = gamma / sqrt(running_var + eps) for every block at once (the expression of bn_apply_kernel)
+__global__ __launch_bounds__(256) void bn_eval_scale_kernel(const float* __restrict__ var, const float* __restrict__ gamma,
+                                                            float eps, size_t n, float* __restrict__ scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) scale[i] = gamma[i] * (1.f / sqrtf(var[i] + eps));
+}
+
+// act[r] = b_out + sum over the column tiles of the epilogue's row-dots, in tile order
+__global__ __launch_bounds__(256) void head_part_sum_kernel(const float* __restrict__ part, int T, int B,
+                                                            const float* __restrict__ b_out, float* __restrict__ act) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= B) return;
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a += part[(size_t)t * B + r];
+    act[r] = a + b_out[0];
+}
+
+static inline size_t eval_fused_ws(const dun_fc_ctx* c) { return (size_t)c->depth * c->W + (size_t)(c->W / 128) * c->B; }
+
+// whole 128 x 128 tiles, enough of them for the LDS-DMA GEMM, one head output, no likelihood pass riding on the head
+static bool eval_fused(const dun_fc_ctx* c) {
+    if (c->train || c->depth == 0 || c->O != 1 || c->obj_y) return false;
+    if (c->W % 128 != 0 || c->B % 128 != 0 || (size_t)(c->B / 128) * (c->W / 128) < 128) return false;
+    if (eval_fused_ws(c) > c->ws_floats) return false;
+    return aligned16(c->H) && aligned16(c->p.w) && aligned16(c->ws);
+}
+
+static int eval_forward_blocks(const dun_fc_ctx* c, hipStream_t s) {
+    const int W = c->W, B = c->B, T = W / 128;
+    float* scale = c->ws;
+    float* part = c->ws + (size_t)c->depth * W;
+    const size_t n = (size_t)c->depth * W;
+    hipLaunchKernelGGL(bn_eval_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->running_var, c->p.gamma,
+                       c->bn_eps, n, scale);
+    DUN_LAUNCH_CHECK();
+    for (int i = 0; i < c->depth; ++i) {
+        dun_gemm_desc g;
+        memset(&g, 0, sizeof(g));
+        g.A = Hd(c, i); g.lda = W; g.a_kcontig = 1;
+        g.B = c->p.w + (size_t)i * W * W; g.ldb = W; g.b_kcontig = 1;
+        g.C = Hd(c, i + 1); g.ldc = W;
+        g.M = B; g.N = W; g.K = W;
+        g.bias = c->p.b + (size_t)i * W;
+        g.relu = 1;
+        if (c->residual) { g.R = Hd(c, i); g.ldr = W; }
+        g.ev_mean = c->running_mean + (size_t)i * W;
+        g.ev_scale = scale + (size_t)i * W;
+        g.ev_shift = c->p.beta + (size_t)i * W;
+        g.ev_head_w = c->p.w_out;
+        g.ev_head_part = part;
+        int rc = gemm_f32(&g, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(head_part_sum_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, part, T, B, c->p.b_out,
+                           c->act + (size_t)(i + 1) * B);
+        DUN_LAUNCH_CHECK();
+    }
+    return DUN_OK;
+}
+
 // the shared head over every depth at once; with the likelihood epilogue when the context asks for it (O == 1)
 static int head(const dun_fc_ctx* c, hipStream_t s) {
     if (c->obj_y && c->O == 1) return head_obj(c, 0, c->depth + 1, s);
@@ -1190,6 +1250,10 @@ extern "C" int dun_fc_forward(const dun_fc_ctx* c, dun_stream_t stream) {
         for (int i = 0; i < c->depth; ++i)
             if ((rc = sn_forward_block(c, i, STREAM))) return rc;
         return head(c, STREAM);
+    }
+    if (eval_fused(c)) {  // inference on whole tiles: each block is ONE GEMM whose epilogue normalises, adds and dots
+        if ((rc = head_obj(c, 0, 1, STREAM))) return rc;
+        return eval_forward_blocks(c, STREAM);
     }
     const bool fused = head_fused(c);  // block_norm(i) writes act[i+1] itself: only depth 0 needs the head kernel
     if (fused && (rc = head_obj(c, 0, 1, STREAM))) return rc;

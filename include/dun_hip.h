@@ -188,6 +188,17 @@ typedef struct dun_gemm_desc {
     const float* bn_rstd;
     float* bnstats;
     int ldz;
+    /* NULL, or the inference form of a trunk block (src/DUN/layers.py:38,42 under model.eval()): BatchNorm with running
+     * statistics is a per-column affine map, so C = [R +] (max(acc + bias, 0) - ev_mean) * ev_scale + ev_shift leaves
+     * the GEMM as the next hidden state (ev_scale = gamma / sqrt(running_var + eps), ev_shift = beta; all [N]).  With
+     * ev_head_w [N] (the shared head's weights, one output) the row-dot of the finished tile is taken as well:
+     * ev_head_part float [N/128][M] receives sum over the tile's 128 columns of C[m][n] ev_head_w[n].  Needs bias and relu,
+     * whole 128 x 128 tiles (>= 128 of them), no colstats / bnz / rank update (DUN_ERR_UNSUPPORTED otherwise). */
+    const float* ev_mean;
+    const float* ev_scale;
+    const float* ev_shift;
+    const float* ev_head_w;
+    float* ev_head_part;
 } dun_gemm_desc;
 int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream);
 /* Measurement hook (no counterpart in the reference; bench.py's in-step roofline): between _begin and _end every

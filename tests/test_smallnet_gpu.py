@@ -140,3 +140,56 @@ def test_small_net_eval_and_truncated_depth():
         assert b1.act.shape[0] == depth + 1
         close(b1.act, b2.act, 2e-5, "eval act_vec at depth %d" % depth)
         close(b1.H, b2.H, 2e-5, "eval hidden states at depth %d" % depth)
+
+
+@pytest.mark.parametrize("B,din,W,L,residual,depth", [(4096, 16, 512, 3, True, 3), (2048, 8, 1024, 2, False, 2),
+                                                       (16384, 4, 128, 2, True, 1), (4096, 16, 512, 3, True, 2),
+                                                       (16384, 8, 1024, 2, True, 2), (32768, 8, 512, 1, False, 1)])   # the last two: 128 x 256 tiles
+def test_inference_epilogue_matches_staged_eval_path(B, din, W, L, residual, depth):
+    """dun_fc_forward in eval mode on whole 128 x 128 tiles: BatchNorm(running stats) + residual + the head's row-dot
+    inside the block GEMM's epilogue (gemm.hip gemm_epilogue_eval) against the staged entries, which write
+    ReLU(Linear) and normalise it in a second pass.  Same per-element arithmetic ((z - mean) * scale + shift), so the
+    hidden states agree to fp32 rounding of the GEMM; the head sums W terms in a different order (1e-5 of the
+    largest magnitude, the bar of src/DUN/training_wrappers.py's predict outputs in DESIGN.md 4)."""
+    model, x, be, g = make(B, din, W, L, 1, residual, seed=11)
+    with torch.no_grad():
+        model.running_mean.copy_(0.1 * torch.randn(L, W, generator=g))
+        model.running_var.copy_(0.5 + torch.rand(L, W, generator=g))
+    model.eval()
+    rm0, rv0, nbt0 = model.running_mean.clone(), model.running_var.clone(), model.num_batches_tracked.clone()
+    b1 = be.fc_buffers(model, B, depth, False)
+    b1.new_act(); b1.set_input(x)
+    b1.H.fill_(float("nan")); b1.act.fill_(float("nan"))
+    be.fc_forward(b1)
+    b2 = be.fc_buffers(model, B, depth, False)
+    b2.new_act(); b2.set_input(x)
+    staged_forward(be, b2, depth, B)
+    assert b1.act.shape[0] == depth + 1 and bool(torch.isfinite(b1.act).all()) and bool(torch.isfinite(b1.H[:depth + 1]).all())
+    close(b1.H[:depth + 1], b2.H[:depth + 1], 1e-5, "eval hidden states")
+    close(b1.act, b2.act, 1e-5, "eval act_vec")
+    # eval mode leaves the running statistics alone
+    assert torch.equal(model.running_mean, rm0) and torch.equal(model.running_var, rv0)
+    assert torch.equal(model.num_batches_tracked, nbt0)
+
+
+def test_inference_epilogue_is_refused_on_ragged_tiles():
+    """The descriptor's ev_* fields on a shape the 128 x 128 LDS-DMA kernel does not take: DUN_ERR_UNSUPPORTED, no launch."""
+    import ctypes as C
+    from dun_amd import _lib, kernels
+    kernels.backend()
+    M, N, K = 300, 100, 100
+    A, Bm = torch.randn(M, K).cuda(), torch.randn(N, K).cuda()
+    Cm = torch.full((M, N), 7.0).cuda()
+    v = torch.ones(N).cuda()
+    d = _lib.GemmDesc()
+    C.memset(C.byref(d), 0, C.sizeof(d))
+    d.A, d.lda, d.a_kcontig = A.data_ptr(), K, 1
+    d.B, d.ldb, d.b_kcontig = Bm.data_ptr(), K, 1
+    d.C, d.ldc = Cm.data_ptr(), N
+    d.M, d.N, d.K = M, N, K
+    d.bias, d.relu = v.data_ptr(), 1
+    d.ev_mean = d.ev_scale = d.ev_shift = v.data_ptr()
+    rc = _lib.lib().dun_gemm_f32(C.byref(d), None)
+    assert rc == 3, rc   # DUN_ERR_UNSUPPORTED (include/dun_hip.h)
+    torch.cuda.synchronize()
+    assert bool((Cm == 7.0).all())
