@@ -389,6 +389,78 @@ def image50_case():
         print("wrote", tag, "D", D, "params", int(out["n_params"]), "fit", out["fit/ret"])
 
 
+def image_exits_case():
+    """Everything BEHIND the convolutional trunk of the C5 constructor (ResNet-50 DUN, D = 12 exits, CIFAR-shaped input,
+    batch 4), pinned so that it can be checked without the trunk: the pooled [D,B,2048] features that reach the shared
+    output_block at every exit (captured by a hook on output_block), and what the reference makes of them --
+    act_vec, ELBO and its gradients w.r.t. act_vec / the features / output_block / q_logits in train mode, and in eval
+    mode act_vec, predict, and fast_forward_impl / fast_predict (src/DUN/stochastic_img_resnets.py:288-302,
+    src/DUN/training_wrappers.py:160-169) under a posterior with one exit below min_prob = 1e-2 (5e-3), one just
+    above it (2e-2) and the rest of the mass on two exits."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.DUN.stochastic_img_resnets import resnet50
+    kw = dict(start_depth=1, end_depth=13, num_classes=10, zero_init_residual=False, initial_conv="1x3",
+              concat_pool=False, input_chanels=3, p_drop=0)
+    torch.manual_seed(0)
+    model = resnet50(arch_uncert=True, **kw)
+    D = model.n_layers
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(4, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (4,), generator=g)
+    pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=False)
+    pm.q_logits.data = 0.3 * torch.randn(D, generator=g)
+    with torch.no_grad():   # a head that is not at its near-zero initial scale: logits of order 1
+        model.output_block.weight.mul_(3.0)
+        model.output_block.bias.copy_(0.1 * torch.randn(10, generator=g))
+    N = 50000
+    net = quiet(DUN_VI, model, pm, N, lr=0.1, momentum=0.9, weight_decay=1e-4, cuda=False, regression=False)
+    out = {"meta": json.dumps(dict(kw=kw, shape=[4, 3, 32, 32], D=D, N=N, lr=0.1, momentum=0.9, wd=1e-4)),
+           "x": npy(x), "y": npy(y), "q_logits0": npy(pm.q_logits),
+           "output_block.weight": npy(model.output_block.weight), "output_block.bias": npy(model.output_block.bias)}
+    seen = []
+    hook = model.output_block.register_forward_pre_hook(lambda mod, inp: seen.append(inp[0]))
+    model.train()
+    act = model.forward(x)
+    act.retain_grad()
+    for f in seen:
+        f.retain_grad()
+    ELBO = pm.estimate_ELBO(model.get_w_prior_loglike(), act, y, net.f_neg_loglike, N, Beta=1)
+    (-ELBO / N).backward()
+    assert len(seen) == D
+    out["train/feat"] = np.stack([npy(f) for f in seen])
+    out["train/g_feat"] = np.stack([npy(f.grad) for f in seen])
+    out["train/act_vec"], out["train/ELBO"], out["train/g_act_vec"] = npy(act), npy(ELBO), npy(act.grad)
+    out["train/g_output_block.weight"] = npy(model.output_block.weight.grad)
+    out["train/g_output_block.bias"] = npy(model.output_block.bias.grad)
+    out["train/g_q_logits"] = npy(pm.q_logits.grad)
+    pm.q_logits.grad = None
+    model.zero_grad()
+    del seen[:]
+    model.eval()
+    with torch.no_grad():
+        out["eval/act_vec"] = npy(model.forward(x))
+        out["eval/feat"] = np.stack([npy(f) for f in seen])
+        del seen[:]
+        pm.current_posterior = pm.get_q_probs().data.clone()   # (what fit leaves behind, src/DUN/training_wrappers.py:226)
+        out["posterior"] = npy(pm.current_posterior)
+        out["eval/ret"] = np.array(net.eval(x, y), dtype=np.float64)
+        del seen[:]
+        out["pred"] = npy(net.predict(x))
+        del seen[:]
+        q = torch.zeros(D)
+        q[2], q[5], q[7], q[11] = 5e-3, 2e-2, 0.6, 0.375
+        net.prob_model.current_posterior = q
+        out["fast/q"] = npy(q)
+        out["fast/act_vec"] = npy(quiet(model.fast_forward_impl, x, q, min_prob=1e-2))
+        del seen[:]
+        out["fast/pred"] = npy(quiet(net.fast_predict, x))
+    hook.remove()
+    zero_rows = [d for d in range(D) if not out["fast/act_vec"][d].any()]
+    assert zero_rows == [0, 1, 2, 3, 4, 6, 8, 9, 10], zero_rows
+    np.savez_compressed(os.path.join(HERE, "img_r50_cifar_exits.npz"), **out)
+    print("wrote img_r50_cifar_exits", "ELBO", float(ELBO), "zero rows", zero_rows, "|act|max", float(np.abs(out["eval/act_vec"]).max()))
+
+
 def uci_case():
     """A tiny synthetic table in the reference's UCI on-disk layout, read by the reference's load_gap_UCI
     (src/datasets/UCI_gap_loader.py:12-60); raw files and outputs go into uci_small.npz."""
@@ -521,6 +593,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "image":
         image_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "exits":
+        image_exits_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "uci":
         uci_case()
         return
@@ -554,6 +629,7 @@ def main():
     head_case()
     image_case()
     image50_case()
+    image_exits_case()
     uci_case()
 
 
