@@ -573,6 +573,7 @@ def run_rank(args):
     else:
         net = build_net(din, W, L, N_train, lr, momentum, wd, cuda=not cpu)
         x, y = shard_data(B_local, din, rank, device)
+    spec = None
     if dist_on:
         from dun_amd.distributed import shard
         spec = shard(net, sync_bn=not args.no_sync_bn)
@@ -655,7 +656,10 @@ def run_rank(args):
             "config": {"workload": "%s: classification DUN_VI.fit, ResNet-50 DUN (start_depth 1, end_depth 13, D=12, "
                                    "10 classes) on %dx%dx%d inputs, global batch %d (%d/GPU), conv trunk on MIOpen, "
                                    "head + CE/ELBO on the HIP kernels" % (args.workload, channels, side, side, B, B_local),
-                       "parallelism": "dp%d batch-sharded, per-replica BatchNorm2d" % world,
+                       "parallelism": "dp%d batch-sharded, %s BatchNorm2d" % (
+                           world, "single-device" if not dist_on else
+                           "synchronised" if (not args.no_sync_bn and spec is not None and spec.sync_bn2d_modules > 0)
+                           else "per-replica"),
                        "distributed": dist_fields(), "train_metrics_last_step": list(last)}}
         if not args.no_kernel_rooflines:
             kr = image_head_rooflines(net, B_local)

@@ -5,6 +5,7 @@ are independent through Linear / ReLU / head / likelihood, so rank r just takes 
 is exchanged explicitly, and nothing else is:
   * BatchNorm batch statistics: fp64 [2,W] sums per block, forward and backward (``sync_bn=True`` reproduces the
     single-device numerics of the full batch; ``False`` gives per-replica statistics like DataParallel would);
+    image DUNs: the same for every BatchNorm2d call of the convolutional trunk, fp64 [2,C] per call (sync_bn.py);
   * the per-depth likelihood sums: one fp64 [D] all-reduce per step (the VI backward does not wait for it);
   * parameter gradients: SUM all-reduce (the loss already carries 1/global_batch), issued per bucket of two blocks
     while the backward of the shallower blocks is still running, so the 2 x 16 MB messages overlap with the GEMMs.
@@ -92,6 +93,11 @@ def shard(net, group=None, sync_bn=True, overlap=True, grad_bucket_blocks=2):
         if spec.world > 1:
             for t in tensors:
                 dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    # image DUNs: every BatchNorm2d of the conv trunk normalises with the statistics of the global batch (sync_bn.py)
+    spec.sync_bn2d_modules = 0
+    if spec.sync_bn:
+        from .sync_bn import convert
+        spec.sync_bn2d_modules = convert(net.model, spec)
     net.model._dist = spec
     net.prob_model._dist = spec
     net._dist = spec

@@ -196,8 +196,133 @@ def _img_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _img_state(net):
+    sd = net.model.state_dict()
+    return {"params": torch.cat([p.data.reshape(-1) for p in net.model.parameters()]).numpy(),
+            "running_mean": torch.cat([v.reshape(-1) for k, v in sd.items() if k.endswith("running_mean")]).numpy(),
+            "running_var": torch.cat([v.reshape(-1) for k, v in sd.items() if k.endswith("running_var")]).numpy(),
+            "num_batches_tracked": torch.stack([v for k, v in sd.items() if k.endswith("num_batches_tracked")]).numpy(),
+            "q_logits": net.prob_model.q_logits.data.numpy().copy()}
+
+
+def _img_sync_worker(rank, world, port, sync_bn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    _record_collectives(log)
+    try:
+        from dun_amd import kernels
+        from dun_amd.distributed import shard
+        from dun_amd.sync_bn import SyncBatchNorm2d
+        from tests.cpu_backend import CpuBackend
+        from tests.test_image_dun import build
+        kernels.set_backend(CpuBackend())
+        c = Case("img_r18")
+        net, meta = build(c, cuda=False)
+        keys = list(net.model.state_dict().keys())
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec = shard(net, sync_bn=sync_bn)
+        n_bn = sum(isinstance(m, torch.nn.BatchNorm2d) for m in net.model.modules())
+        assert spec.sync_bn2d_modules == (n_bn if sync_bn else 0) and n_bn > 0
+        assert all(isinstance(m, SyncBatchNorm2d) == sync_bn for m in net.model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        assert list(net.model.state_dict().keys()) == keys       # re-classed in place: checkpoints stay interchangeable
+        x, y = c.t("x"), c.t("y").long()
+        B = x.shape[0] // world
+        xs, ys = x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B]
+        rets = [net.fit(xs, ys) for _ in range(2)]
+        ev = net.eval(xs, ys)
+        ret[rank] = (rets, ev, _img_state(net), log)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_image_dun_two_ranks_match_single_process(world):
+    """Image DUN under shard(sync_bn=True): every BatchNorm2d call of the conv trunk -- blocks, adapt stacks and the
+    tail each exit runs again -- normalises with the statistics of the global batch (dun_amd/sync_bn.py), so ranks on
+    slices of the img_r18 batch (6 rows: 3 + 3, or 2 + 2 + 2) reproduce the single-process steps on all 6 rows."""
+    from dun_amd import kernels
+    from tests.cpu_backend import CpuBackend
+    from tests.test_image_dun import build
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_img_sync_worker, args=(world, _free_port(), True, ret), nprocs=world, join=True)
+    kernels.set_backend(CpuBackend())
+    try:
+        c = Case("img_r18")
+        net, _ = build(c, cuda=False)
+        x, y = c.t("x"), c.t("y").long()
+        rets = [net.fit(x, y) for _ in range(2)]
+        ev = net.eval(x, y)
+        st = _img_state(net)
+    finally:
+        kernels.set_backend(None)
+    for r in range(world):
+        for a, s in zip(ret[r][0], rets):
+            assert np.allclose(a, s, rtol=2e-5, atol=1e-7), (r, a, s)      # objective, nll, err of the GLOBAL batch
+        # eval runs on the rank's own rows with the (synchronised) running statistics: compare what is comparable
+        assert np.all(np.isfinite(ret[r][1]))
+        for k, v in st.items():
+            scale = np.abs(v).max()
+            assert np.abs(ret[r][2][k] - v).max() <= 2e-5 * scale + 1e-7, (r, k)
+            assert np.array_equal(ret[r][2][k], ret[0][2][k]), k             # replicas stay bit-identical
+        assert ret[r][3] == ret[0][3] and len(ret[r][3]) > 0                 # same collectives, same order
+    # the per-call exchanges are there: fp64 [2,C] messages, forward and backward
+    kinds = {(e[1], e[2]) for e in ret[0][3] if e[0] == "all_reduce"}
+    assert ((2, 64), "torch.float64") in kinds and ((2, 512), "torch.float64") in kinds
+
+
+def test_image_dun_per_replica_batchnorm_differs():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_img_sync_worker, args=(2, _free_port(), False, ret), nprocs=2, join=True)
+    ret2 = mgr.dict()
+    mp.spawn(_img_sync_worker, args=(2, _free_port(), True, ret2), nprocs=2, join=True)
+    assert np.array_equal(ret[0][2]["params"], ret[1][2]["params"])          # gradients are still summed
+    assert not np.array_equal(ret[0][2]["running_mean"], ret[1][2]["running_mean"])   # statistics of different rows
+    assert abs(ret[0][0][0][0] - ret2[0][0][0][0]) > 1e-6 * abs(ret2[0][0][0][0])  # a different computation
+
+
+def test_sync_batchnorm2d_gradients_match_full_batch_autograd():
+    """The Function alone, one rank with collectives forced (a one-rank all-reduce is the identity): forward, running
+    statistics and all three gradients against nn.BatchNorm2d's own autograd on the same input in fp64."""
+    port = _free_port()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from dun_amd.distributed import Shard
+        from dun_amd.sync_bn import convert
+        spec = Shard()
+        spec.force_collectives = True
+        g = torch.Generator().manual_seed(3)
+        for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+            ref = torch.nn.BatchNorm2d(5).to(dtype)
+            with torch.no_grad():
+                ref.weight.copy_(torch.randn(5, generator=g)); ref.bias.copy_(torch.randn(5, generator=g))
+            mine = torch.nn.Sequential(torch.nn.BatchNorm2d(5).to(dtype))
+            mine[0].load_state_dict(ref.state_dict())
+            assert convert(mine, spec) == 1
+            x = (3.0 + 2.0 * torch.randn(4, 5, 3, 2, generator=g)).to(dtype)
+            dy = torch.randn(4, 5, 3, 2, generator=g).to(dtype)
+            xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            ya, yb = ref(xa), mine(xb)
+            ya.backward(dy); yb.backward(dy)
+            for a, b in ((ya, yb), (xa.grad, xb.grad), (ref.weight.grad, mine[0].weight.grad), (ref.bias.grad, mine[0].bias.grad),
+                         (ref.running_mean, mine[0].running_mean), (ref.running_var, mine[0].running_var)):
+                assert float((a - b).detach().abs().max()) <= tol * max(1.0, float(a.detach().abs().max()))
+            assert int(mine[0].num_batches_tracked) == 1
+            mine[0].load_state_dict(ref.state_dict())
+            mine.eval(); ref.eval()
+            assert torch.equal(mine(x), ref(x))          # eval mode is nn.BatchNorm2d's own path
+    finally:
+        dist.destroy_process_group()
+
+
 def test_image_dun_two_ranks_stay_identical():
-    """Image DUN (conv trunk in torch, per-replica BatchNorm2d): loose-parameter gradients are SUM all-reduced."""
+    """Image DUN (conv trunk in torch, synchronised BatchNorm2d by default): loose-parameter gradients are SUM
+    all-reduced, replicas that started different are made identical and stay so."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_img_worker, args=(2, _free_port(), ret), nprocs=2, join=True)

@@ -426,6 +426,22 @@ def test_sharded_path_world1_matches_unsharded():
         assert torch.equal(net.model.flat_params, ref.model.flat_params)
         assert torch.equal(net.model.running_var, ref.model.running_var)
         assert np.allclose(net.eval(x, y), ref.eval(x, y), rtol=1e-6)
+        # image DUN: every BatchNorm2d call through dun_amd/sync_bn.py with its fp64 [2,C] exchange issued on RCCL
+        # (one rank: the sums come back unchanged) against MIOpen's own BatchNorm in the unsharded step
+        from tests.test_image_dun import build as build_img
+        ci = Case("img_r18")
+        xi, yi = ci.t("x"), ci.t("y").long()
+        ref_i, _ = build_img(ci, cuda=True)
+        want_i = [ref_i.fit(xi, yi) for _ in range(2)]
+        net_i, _ = build_img(ci, cuda=True)
+        spec_i = quiet(shard, net_i, sync_bn=True)
+        spec_i.force_collectives = True
+        assert spec_i.sync_bn2d_modules > 0
+        got_i = [net_i.fit(xi, yi) for _ in range(2)]
+        assert np.allclose(got_i, want_i, rtol=2e-5, atol=1e-7), (got_i, want_i)
+        for (k, a), b in zip(net_i.model.state_dict().items(), ref_i.model.state_dict().values()):
+            scale = max(float(b.abs().max()), 1e-30) if b.is_floating_point() else 1.0
+            assert float((a.double() - b.double()).abs().max()) <= 2e-5 * scale + 1e-7, k
     finally:
         dist.destroy_process_group()
 
