@@ -161,6 +161,111 @@ def test_per_replica_batchnorm_differs():
     assert np.abs(r0[2]["rm"] - st["rm"]).max() > 0
 
 
+# ---- the shapes an 8-GPU run meets: more ranks, ragged gradient buckets, every switch of shard() ----------------------
+def _syn_net(cfg):
+    """A seeded synthetic DUN (no fixture): din 6, width 32, cfg['L'] blocks, regression, VI or exact marginal."""
+    from dun_amd import kernels
+    from dun_amd.probability import depth_categorical, depth_categorical_VI
+    from dun_amd.stochastic_fc_models import arq_uncert_fc_resnet
+    from dun_amd.training_wrappers import DUN, DUN_VI
+    from tests.cpu_backend import CpuBackend
+    kernels.set_backend(CpuBackend())
+    torch.manual_seed(7)
+    L = cfg["L"]
+    model = arq_uncert_fc_resnet(6, 1, 32, L)
+    pm = (depth_categorical_VI if cfg["vi"] else depth_categorical)([1.0 / (L + 1)] * (L + 1), cuda=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = (DUN_VI if cfg["vi"] else DUN)(model, pm, 96, lr=0.05, momentum=0.9, weight_decay=1e-4, cuda=False,
+                                             regression=True)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(96, 6, generator=g)      # 96 rows: 48 / 32 / 24 per rank
+    y = torch.tanh(x[:, :1] - 0.5 * x[:, 1:2]) + 0.1 * torch.randn(96, 1, generator=g)
+    return net, x, y
+
+
+def _syn_worker(rank, world, port, cfg, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    _record_collectives(log)
+    try:
+        from dun_amd.distributed import shard
+        net, x, y = _syn_net(cfg)
+        if rank != 0:
+            net.model.flat_params.add_(0.25 * rank)      # shard() must make the replicas identical
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec = shard(net, sync_bn=cfg["sync_bn"], overlap=cfg["overlap"], grad_bucket_blocks=cfg["buckets"])
+        assert spec.world == world and spec.grad_bucket_blocks == cfg["buckets"]
+        B = x.shape[0] // world
+        xs, ys = x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B]
+        rets = [net.fit(xs, ys) for _ in range(3)]
+        ret[rank] = (rets, {k: v.numpy() for k, v in _state(net).items()}, log)
+    finally:
+        dist.destroy_process_group()
+
+
+def _syn_single(cfg):
+    from dun_amd import kernels
+    try:
+        net, x, y = _syn_net(cfg)
+        rets = [net.fit(x, y) for _ in range(3)]
+        return rets, {k: v.numpy() for k, v in _state(net).items()}
+    finally:
+        kernels.set_backend(None)
+
+
+@pytest.mark.parametrize("world,L,buckets,overlap,vi", [
+    (4, 5, 1, True, True),      # one message per block
+    (4, 5, 2, True, True),      # 5 blocks in buckets of two: a ragged bucket
+    (4, 5, 3, True, True),      # 3 + 2
+    (2, 5, 3, False, True),     # blocking gradient all-reduces
+    (4, 5, 2, True, False),     # exact marginal likelihood (DUN): the per-depth sums gate the backward
+    (3, 4, 8, False, False),    # a bucket larger than the net, an odd world size
+])
+def test_more_ranks_and_ragged_gradient_buckets_match_single_process(world, L, buckets, overlap, vi):
+    cfg = dict(L=L, buckets=buckets, overlap=overlap, vi=vi, sync_bn=True)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_syn_worker, args=(world, _free_port(), cfg, ret), nprocs=world, join=True)
+    rets, st = _syn_single(cfg)
+    for r in range(world):
+        for a, s_ in zip(ret[r][0], rets):
+            assert np.allclose(a, s_, rtol=2e-5, atol=1e-6, equal_nan=True), (r, a, s_)
+        for k in st:
+            assert np.array_equal(ret[r][1][k], ret[0][1][k]), (r, k)            # replicas bit-identical
+            scale = np.abs(st[k]).max()
+            assert np.abs(ret[r][1][k] - st[k]).max() <= 2e-5 * scale + 1e-7, (r, k)
+        assert ret[r][2] == ret[0][2], [(i, a, b) for i, (a, b) in enumerate(zip(ret[r][2], ret[0][2])) if a != b][:3]
+    # the gradient messages follow the bucket size: block weights travel as ceil(L / buckets) messages per step
+    log = ret[0][2]
+    w_msgs = [e for e in log if e[0] == "all_reduce" and e[2] == "torch.float32" and len(e[1]) == 3]
+    per_step = [e[1][0] for e in w_msgs[:len(w_msgs) // 3]]
+    full, rest = divmod(L, buckets)
+    assert per_step == [buckets] * full + ([rest] if rest else []), per_step       # deepest blocks first, ragged last bucket
+    assert len(w_msgs) == 3 * len(per_step) and all(e[1][1:] == (32, 32) for e in w_msgs)
+    # everything else of the flat gradient buffer (the `exclude=` slicing around the block weights): 1-D pieces
+    flat_msgs = [e for e in log if e[0] == "all_reduce" and e[2] == "torch.float32" and len(e[1]) == 1 and e[1][0] > 32]
+    assert len(flat_msgs) >= 3
+    assert all(e[3] == overlap for e in w_msgs + flat_msgs)
+
+
+def test_four_ranks_per_replica_batchnorm():
+    cfg = dict(L=5, buckets=2, overlap=True, vi=True, sync_bn=False)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_syn_worker, args=(4, _free_port(), cfg, ret), nprocs=4, join=True)
+    rets, st = _syn_single(cfg)
+    for r in range(1, 4):
+        assert np.array_equal(ret[r][1]["flat"], ret[0][1]["flat"])               # parameters: summed gradients, identical
+        assert np.array_equal(ret[r][1]["q"], ret[0][1]["q"])
+        assert not np.array_equal(ret[r][1]["rm"], ret[0][1]["rm"])               # statistics of each rank's own rows
+        assert ret[r][2] == ret[0][2]
+    assert not any(e[0] == "all_reduce" and e[1] == (2, 32) for e in ret[0][2])   # no BatchNorm exchange at all
+    assert np.abs(ret[0][1]["flat"] - st["flat"]).max() > 1e-6                     # a different computation
+
+
 def _img_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
