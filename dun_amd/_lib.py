@@ -22,7 +22,7 @@ EXPORTS = [
     "dun_fc_workspace_floats", "dun_fc_obj_num_partials", "dun_fc_head_is_fused", "dun_fc_forward", "dun_fc_backward", "dun_fc_input_layer", "dun_fc_block_linear",
     "dun_fc_block_norm", "dun_fc_block_apply", "dun_fc_head", "dun_fc_head_depth", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply", "dun_fc_bwd_block_dx", "dun_fc_bwd_block_dw",
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
-    "dun_sgd_step_multi", "dun_predict_gauss_step", "dun_fc_small_net_mode", "dun_fc_sync_bytes", "dun_fc_sync_status",
+    "dun_sgd_step_multi", "dun_sgd_step_multi_gated", "dun_label_count_bad", "dun_predict_gauss_step", "dun_fc_small_net_mode", "dun_fc_sync_bytes", "dun_fc_sync_status",
     "dun_fc_objective_in_forward", "dun_fc_head_grads_in_forward", "dun_copy_pair",
     "dun_copy_pair_indirect", "dun_predict_gauss_step_signal", "dun_gemm_profile_begin", "dun_gemm_profile_end",
 ]
@@ -129,6 +129,8 @@ def _declare(lib):
         "dun_head_backward": (i, [vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]),
         "dun_sgd_step": (i, [vp, vp, vp, sz, f, f, f, vp]),
         "dun_sgd_step_multi": (i, [C.POINTER(SgdSegment), i, f, f, f, vp]),
+        "dun_sgd_step_multi_gated": (i, [C.POINTER(SgdSegment), i, f, f, f, vp, vp]),
+        "dun_label_count_bad": (i, [vp, C.c_size_t, i, vp, vp]),
         "dun_predict_gauss_step": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "dun_fc_small_net_mode": (i, [i]),
         "dun_fc_sync_bytes": (sz, [i, i]),

@@ -1352,9 +1352,11 @@ namespace dun {
 struct SgdSegs {
     dun_sgd_segment seg[DUN_SGD_MAX_SEGMENTS];
     int nseg;
+    const double* gate;  // nullptr, or a device count: the launch changes nothing when it is positive
 };
 // grid (workgroups per segment, segments); element by element (any alignment), the arithmetic of sgd_kernel
 __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdSegs a, float lr, float momentum, float wd) {
+    if (a.gate != nullptr && *a.gate > 0.0) return;  // (uniform: every workgroup reads the same word)
     const dun_sgd_segment sg = a.seg[blockIdx.y];
     float* __restrict__ p = sg.p;
     const float* __restrict__ g = sg.g;
@@ -1393,13 +1395,51 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(SgdSegs a, float lr, flo
 }
 }  // namespace dun
 
+// number of labels outside [0, C) other than the ignored -100: one workgroup (label vectors are a batch long)
+namespace dun {
+__global__ __launch_bounds__(256) void label_count_bad_kernel(const long long* __restrict__ y, size_t n, int C,
+                                                              double* __restrict__ count) {
+    __shared__ double red[4];
+    double bad = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        const long long v = y[i];
+        bad += ((v < 0 || v >= (long long)C) && v != -100) ? 1.0 : 0.0;
+    }
+    const double t = block_sum<256, double>(bad, red);
+    if (threadIdx.x == 0) count[0] = t;
+}
+}  // namespace dun
+
+extern "C" int dun_label_count_bad(const int64_t* y, size_t n, int C, double* count, dun_stream_t stream) {
+    DUN_REQUIRE(count != nullptr && (n == 0 || y != nullptr) && C > 0, "dun_label_count_bad: null pointer or C=%d", C);
+    hipLaunchKernelGGL(label_count_bad_kernel, dim3(1), dim3(256), 0, STREAM, reinterpret_cast<const long long*>(y), n, C,
+                       count);
+    DUN_LAUNCH_CHECK();
+    return DUN_OK;
+}
+
+static int sgd_multi_impl(const dun_sgd_segment* segments, int nseg, float lr, float momentum, float weight_decay,
+                          const double* gate, dun_stream_t stream);
+
 extern "C" int dun_sgd_step_multi(const dun_sgd_segment* segments, int nseg, float lr, float momentum, float weight_decay,
                                   dun_stream_t stream) {
+    return sgd_multi_impl(segments, nseg, lr, momentum, weight_decay, nullptr, stream);
+}
+
+extern "C" int dun_sgd_step_multi_gated(const dun_sgd_segment* segments, int nseg, float lr, float momentum,
+                                        float weight_decay, const double* skip_if_positive, dun_stream_t stream) {
+    DUN_REQUIRE(skip_if_positive != nullptr, "dun_sgd_step_multi_gated: null gate");
+    return sgd_multi_impl(segments, nseg, lr, momentum, weight_decay, skip_if_positive, stream);
+}
+
+static int sgd_multi_impl(const dun_sgd_segment* segments, int nseg, float lr, float momentum, float weight_decay,
+                          const double* gate, dun_stream_t stream) {
     DUN_REQUIRE(nseg >= 0 && nseg <= DUN_SGD_MAX_SEGMENTS, "dun_sgd_step_multi: %d segments (at most %d)", nseg,
                 DUN_SGD_MAX_SEGMENTS);
     DUN_REQUIRE(nseg == 0 || segments != nullptr, "dun_sgd_step_multi: null segments");
     SgdSegs a;
     memset(&a, 0, sizeof(a));
+    a.gate = gate;
     size_t nmax = 0;
     for (int k = 0; k < nseg; ++k) {
         DUN_REQUIRE(segments[k].n == 0 || (segments[k].p && segments[k].g && segments[k].buf),

@@ -382,16 +382,33 @@ class HipBackend(object):
                                                dst1.numel() * dst1.element_size(), L.out_ptr(table),
                                                L.stream_ptr(dst0.device)), "dun_copy_pair_indirect")
 
-    def sgd_step_multi(self, triples, lr, momentum, weight_decay):
-        """The same update over several (param, grad, momentum buffer) triples, DUN_SGD_MAX_SEGMENTS per launch."""
+    def sgd_step_multi(self, triples, lr, momentum, weight_decay, gate=None):
+        """The same update over several (param, grad, momentum buffer) triples, DUN_SGD_MAX_SEGMENTS per launch.
+        ``gate``: a device double (``label_gate``); when it is positive the launches change nothing."""
         lib = L.lib()
         for k in range(0, len(triples), L.SGD_MAX_SEGMENTS):
             chunk = triples[k:k + L.SGD_MAX_SEGMENTS]
             segs = (L.SgdSegment * len(chunk))()
             for sg, (p, g, b) in zip(segs, chunk):
                 sg.p, sg.g, sg.buf, sg.n = L.f32(p), L.f32(g), L.f32(b), p.numel()
-            L.check(lib.dun_sgd_step_multi(segs, len(chunk), float(lr), float(momentum), float(weight_decay),
-                                           L.stream_ptr(chunk[0][0].device)), "dun_sgd_step_multi")
+            if gate is None:
+                L.check(lib.dun_sgd_step_multi(segs, len(chunk), float(lr), float(momentum), float(weight_decay),
+                                               L.stream_ptr(chunk[0][0].device)), "dun_sgd_step_multi")
+            else:
+                L.check(lib.dun_sgd_step_multi_gated(segs, len(chunk), float(lr), float(momentum), float(weight_decay),
+                                                     L.ptr(gate), L.stream_ptr(chunk[0][0].device)),
+                        "dun_sgd_step_multi_gated")
+
+    def label_gate(self, y, C):
+        """Device double [1]: how many labels are outside [0, C) and not the ignored -100 (nn.CrossEntropyLoss raises on
+        those before any update; the step's SGD launches take this count as their gate)."""
+        y = y.contiguous()
+        if y.dtype != torch.int64:
+            raise TypeError("label_gate: int64 labels, got %s" % y.dtype)
+        out = torch.empty(1, device=y.device, dtype=torch.float64)
+        L.check(L.lib().dun_label_count_bad(L.ptr(y), y.numel(), int(C), L.ptr(out), L.stream_ptr(y.device)),
+                "dun_label_count_bad")
+        return out
 
     # ---- raw GEMM (tests / benchmarks) ----------------------------------------------------------------
     def gemm(self, A, B, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, relu=False, R=None, U=None, V=None,

@@ -103,6 +103,21 @@ class DUN(BaseNet):
             for g, r in zip(loose, torch._utils._unflatten_dense_tensors(flat, loose)):
                 g.copy_(r)
 
+    def _label_gate(self, y, act_vec):
+        """Classification: the count of labels nn.CrossEntropyLoss would raise on (outside [0, C), not -100), on the
+        device; the optimiser's launches leave parameters and momentum alone when it is positive, and `_metrics_host`
+        raises the IndexError once the step's host copy is home -- so a caller that catches it, or a checkpoint written
+        afterwards, holds the parameters from before the step, as with the reference (which raises before its update)."""
+        if self.regression:
+            return None
+        gate_fn = getattr(kernels.backend(), "label_gate", None)
+        if gate_fn is None:
+            return None
+        gate = gate_fn(y, act_vec.shape[-1])
+        if self._dist is not None:
+            self._dist.all_reduce(gate)     # one rank's bad label stops every replica's update
+        return gate
+
     def _metrics_device(self, act_vec, y, objective, q_logits=None):
         """Device side of the returned scalars: ([objective,] nll_sum, err_sum) as one fp64 tensor + the divisor.
         ``q_logits`` (DUN_VI.fit): the metrics use q = softmax(q_logits), which also becomes ``current_posterior``."""
@@ -292,7 +307,7 @@ class DUN(BaseNet):
         out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train,
                                               head_pass=head_pass)
         self._backward(act_vec, prior_loglikes, out)
-        self.optimizer.step()
+        self.optimizer.step(gate=self._label_gate(y, act_vec))
         # this posterior is one iteration behind the parameters: estimated with the acts from before the step
         self.prob_model.current_posterior = out.posterior.clone()
         return self._metrics_device(act_vec, y, out.log_marg)
@@ -412,7 +427,7 @@ class DUN_VI(DUN):
         out = self.prob_model.fused_objective(prior_loglikes, act_vec, y, self.f_neg_loglike, self.N_train, Beta=1,
                                               head_pass=head_pass)
         self._backward(act_vec, prior_loglikes, out)
-        self.optimizer.step()
+        self.optimizer.step(gate=self._label_gate(y, act_vec))
         # train metrics with the POST-step q(d), which also becomes current_posterior (training_wrappers.py:229-242)
         return self._metrics_device(act_vec, y, out.objective, q_logits=self.prob_model.q_logits)
 

@@ -396,6 +396,16 @@ typedef struct dun_sgd_segment {
 int dun_sgd_step_multi(const dun_sgd_segment* segments /* host array */, int nseg, float lr, float momentum,
                        float weight_decay, dun_stream_t stream);
 
+/* The guard of nn.CrossEntropyLoss / nn.NLLLoss (src/DUN/training_wrappers.py:29-30, used at :205 and :112), which
+ * raise on a label outside [0, C) before anything is updated.  A device step cannot raise in the middle, so:
+ * dun_label_count_bad writes (not adds) into count[0] how many of y[0..n) are outside [0, C) and not the ignored -100
+ * (one workgroup), and dun_sgd_step_multi_gated is dun_sgd_step_multi that changes NOTHING -- parameters and momentum
+ * buffers -- when *skip_if_positive > 0 (a device double, e.g. that count, all-reduced when the batch is sharded).
+ * The wrappers raise the reference's IndexError from the same count once the step's one host copy is home. */
+int dun_label_count_bad(const int64_t* y, size_t n, int C, double* count, dun_stream_t stream);
+int dun_sgd_step_multi_gated(const dun_sgd_segment* segments, int nseg, float lr, float momentum, float weight_decay,
+                             const double* skip_if_positive, dun_stream_t stream);
+
 /* Two device-to-device copies in ONE launch (the inputs of a captured training step go into its static buffers:
  * x and y of src/DUN/training_wrappers.py:215; host glue, no arithmetic).  Byte counts; any alignment. */
 int dun_copy_pair(void* dst0, const void* src0, size_t bytes0, void* dst1, const void* src1, size_t bytes1,

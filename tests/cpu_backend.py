@@ -296,6 +296,10 @@ class CpuBackend(object):
     def head_backward(self, H, w, dact, need_dH=True):
         return dact.t() @ H, dact.sum(0), (dact @ w if need_dH else None)
 
+    def label_gate(self, y, C):
+        bad = ((y < 0) | (y >= C)) & (y != -100)
+        return bad.sum().to(torch.float64).reshape(1)
+
     def sgd_step(self, p, g, buf, lr, momentum, weight_decay):
         ge = g + weight_decay * p
         buf.mul_(momentum).add_(ge)

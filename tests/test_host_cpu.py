@@ -166,13 +166,44 @@ def check_label_semantics_through_the_wrapper(net_builder):
         assert np.allclose(got, want, rtol=2e-5 if step == 0 else 5e-3), (got, want)
     onet.current_posterior = onet.current_posterior.detach()
     assert np.allclose(net.eval(x, y), onet.evaluate(x, y), rtol=5e-3)
-    for bad in (10, -1):
-        yb = c.y().clone()
-        yb[5] = bad
-        with pytest.raises(IndexError):
-            net_builder(c).fit(x, yb)
-        with pytest.raises(IndexError):
-            net.eval(x, yb)
+    def snapshot(n):
+        st = {"flat": n.model.flat_params.detach().clone()}
+        for i, p in enumerate(n.prob_model.parameters()):
+            st["prob%d" % i] = p.detach().clone()
+        for i, (k, v) in enumerate(sorted(n.optimizer.state.items(), key=lambda kv: id(kv[0]))):
+            for name, t in v.items():
+                if torch.is_tensor(t):
+                    st["opt%d/%s" % (i, name)] = t.detach().clone()
+        return st
+
+    for name in ("cls_fc", "cls_fc_mll"):          # q_logits is a parameter in the first, there is none in the second
+        c2 = Case(name)
+        for bad in (10, -1):
+            yb = c2.y().clone()
+            yb[5] = bad
+            nb = net_builder(c2)
+            nb.fit(x, c2.y())                        # a valid step first: momentum buffers exist and are not zero
+            before = snapshot(nb)
+            assert len(before) >= 2
+            with pytest.raises(IndexError):
+                nb.fit(x, yb)
+            after = snapshot(nb)
+            # the reference raises inside the loss, BEFORE its update: nothing the optimiser owns may have moved, and
+            # in particular the NaN objective of such a batch must not have reached q_logits or a momentum buffer
+            assert sorted(after) == sorted(before)
+            for k in before:
+                assert bool(torch.isfinite(after[k]).all()), k
+                assert torch.equal(after[k], before[k]), k
+            with pytest.raises(IndexError):
+                nb.fit(x, yb)                        # (and again: on the GPU this is a replay of the captured step)
+            assert all(torch.equal(v, before[k]) for k, v in snapshot(nb).items())
+            ret = nb.fit(x, c2.y())                  # training goes on from where it was
+            assert np.all(np.isfinite(np.array(ret, dtype=np.float64)[[0, 2]]))
+            assert not torch.equal(nb.model.flat_params, before["flat"])
+    yb = c.y().clone()
+    yb[5] = 10
+    with pytest.raises(IndexError):
+        net.eval(x, yb)
 
 
 def test_label_semantics_through_the_wrapper(cpu_backend):
