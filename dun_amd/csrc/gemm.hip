@@ -1025,11 +1025,11 @@ struct GemmProfSlot {
     dun_gemm_profile_rec rec;
 };
 static GemmProfSlot* g_prof = nullptr;
-static int g_prof_cap = 0, g_prof_n = 0;
+static int g_prof_cap = 0, g_prof_n = 0, g_prof_lim = 0;  // slots allocated, used, allowed in this window
 static bool g_prof_on = false;
 
 static GemmProfSlot* gemm_profile_open(const dun_gemm_desc* d, int kernel, int ksplit, hipStream_t s) {
-    if (!g_prof_on || g_prof_n >= g_prof_cap) return nullptr;
+    if (!g_prof_on || g_prof_n >= g_prof_lim) return nullptr;
     GemmProfSlot* slot = &g_prof[g_prof_n++];
     dun_gemm_profile_rec& r = slot->rec;
     r.M = d->M; r.N = d->N; r.K = d->K;
@@ -1179,6 +1179,7 @@ extern "C" int dun_gemm_profile_begin(int max_launches) {
         g_prof_cap = max_launches;
     }
     g_prof_n = 0;
+    g_prof_lim = max_launches;
     g_prof_on = true;
     return DUN_OK;
 }

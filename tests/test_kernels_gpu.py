@@ -423,3 +423,97 @@ def test_errors_are_loud(be):
         be.ll_pass(dev(torch.zeros(3, 5, 2)), dev(torch.zeros(5, 2)), True, dev(torch.zeros(2)), None, False, 1.0)
     with pytest.raises(RuntimeError):
         be.ll_pass(dev(torch.zeros(2, 3, 2000)), dev(torch.zeros(3).long()), False, None, None, False, 1.0)
+
+
+def test_multi_tensor_sgd_matches_torch_and_respects_its_gate(be):
+    """dun_sgd_step_multi / _gated over tensors of awkward sizes and alignments (a 4-byte-offset view among them), more
+    segments than one launch takes (DUN_SGD_MAX_SEGMENTS = 24), against torch.optim.SGD; with a positive gate nothing
+    moves, with a zero gate everything does."""
+    from dun_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 3, 4, 10007, 100, 4096, 13] + [17 + k for k in range(24)]
+    assert len(sizes) > _lib.SGD_MAX_SEGMENTS
+    p0 = [torch.randn(n, generator=g) for n in sizes]
+    refs = [torch.nn.Parameter(t.clone()) for t in p0]
+    opt = torch.optim.SGD(refs, lr=0.05, momentum=0.9, weight_decay=1e-3)
+    store = torch.zeros(sum(sizes) + 1, device="cuda")      # parameters packed behind a 1-float offset: unaligned views
+    ps, off = [], 1
+    for t in p0:
+        v = store[off:off + t.numel()]
+        v.copy_(t)
+        ps.append(v)
+        off += t.numel()
+    bufs = [torch.zeros(n, device="cuda") for n in sizes]
+    zero, one = torch.zeros(1, device="cuda", dtype=torch.float64), torch.ones(1, device="cuda", dtype=torch.float64)
+    for step in range(3):
+        grads = [torch.randn(n, generator=g) for n in sizes]
+        for r, gr in zip(refs, grads):
+            r.grad = gr.clone()
+        opt.step()
+        triples = [(p, dev(gr), b) for p, gr, b in zip(ps, grads, bufs)]
+        before = store.clone()
+        be.sgd_step_multi(triples, 0.05, 0.9, 1e-3, gate=one)          # gated off: parameters and momentum untouched
+        assert torch.equal(store, before) and (step > 0 or all(not bool(b.any()) for b in bufs))
+        if step == 1:
+            be.sgd_step_multi(triples, 0.05, 0.9, 1e-3, gate=zero)
+        else:
+            be.sgd_step_multi(triples, 0.05, 0.9, 1e-3)
+    for p, r in zip(ps, refs):
+        assert rel_err(p.cpu(), r.data) < 1e-6
+    assert float(store[0]) == 0.0
+
+
+def test_label_gate_counts_what_cross_entropy_raises_on(be):
+    y = torch.tensor([0, 9, -100, 10, -1, 3, -100, 1 << 40], dtype=torch.int64, device="cuda")
+    assert float(be.label_gate(y, 10)) == 3.0
+    assert float(be.label_gate(y[:3], 10)) == 0.0
+    assert float(be.label_gate(y[:0], 10)) == 0.0
+    big = torch.randint(0, 7, (100003,), generator=torch.Generator().manual_seed(1)).cuda()
+    assert float(be.label_gate(big, 7)) == 0.0 and float(be.label_gate(big, 6)) == float((big == 6).sum())
+    with pytest.raises(TypeError):
+        be.label_gate(y.int(), 10)
+
+
+def test_copy_pair_direct_and_through_the_pointer_table(be):
+    g = torch.Generator().manual_seed(2)
+    for n0, n1 in ((512 * 13, 512), (7, 3), (1, 100001)):
+        a, b = torch.randn(n0, generator=g).cuda(), torch.randn(n1, generator=g).cuda()
+        d0, d1 = torch.zeros(n0 + 2, device="cuda"), torch.zeros(n1 + 2, device="cuda")
+        be.copy_pair(d0[1:-1], a, d1[1:-1], b)                        # (destinations at a 4-byte offset: the byte path)
+        assert torch.equal(d0[1:-1], a) and torch.equal(d1[1:-1], b)
+        assert float(d0[0]) == 0 and float(d0[-1]) == 0 and float(d1[0]) == 0 and float(d1[-1]) == 0
+        table = torch.zeros(2, dtype=torch.int64).pin_memory()
+        e0, e1 = torch.zeros(n0, device="cuda"), torch.zeros(n1, device="cuda")
+        for src0, src1 in ((a, b), (a + 1, b - 1)):                   # the table is read when the launch RUNS
+            table[0], table[1] = src0.data_ptr(), src1.data_ptr()
+            be.copy_pair_indirect(e0, e1, table)
+            torch.cuda.synchronize()
+            assert torch.equal(e0, src0) and torch.equal(e1, src1)
+
+
+def test_gemm_profile_window_reports_every_launch(be):
+    """dun_gemm_profile_begin/_end (bench.py's in-step roofline): shapes, kernel family and a plausible duration per
+    dun_gemm_f32 launch inside the window; misuse is refused; outside the window nothing is recorded."""
+    import ctypes as C
+    from dun_amd import _lib
+    lib = _lib.lib()
+    A, Bm = torch.randn(4096, 256).cuda(), torch.randn(512, 256).cuda()
+    small_a, small_b = torch.randn(100, 30).cuda(), torch.randn(50, 30).cuda()
+    be.gemm(A, Bm, 4096, 512, 256)                                       # outside: not recorded
+    assert lib.dun_gemm_profile_begin(8) == 0
+    assert lib.dun_gemm_profile_begin(8) != 0                            # one window at a time
+    for _ in range(3):
+        be.gemm(A, Bm, 4096, 512, 256)
+    be.gemm(small_a, small_b, 100, 50, 30)
+    recs = (_lib.GemmProfileRec * 8)()
+    n = lib.dun_gemm_profile_end(recs, 8)
+    assert n == 4
+    for r in recs[:3]:
+        assert (r.M, r.N, r.K) == (4096, 512, 256) and 0.0 < r.ms < 5.0
+    assert (recs[3].M, recs[3].N, recs[3].K) == (100, 50, 30) and recs[3].ms > 0.0
+    assert recs[0].kernel != recs[3].kernel                              # LDS-DMA tiles vs the register-staged kernel
+    assert lib.dun_gemm_profile_end(recs, 8) == 0                        # no window open: nothing to report
+    assert lib.dun_gemm_profile_begin(2) == 0
+    for _ in range(3):
+        be.gemm(small_a, small_b, 100, 50, 30)                           # more launches than slots: the extra one is dropped
+    assert lib.dun_gemm_profile_end(recs, 8) == 2

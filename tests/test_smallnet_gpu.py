@@ -193,3 +193,67 @@ def test_inference_epilogue_is_refused_on_ragged_tiles():
     assert rc == 3, rc   # DUN_ERR_UNSUPPORTED (include/dun_hip.h)
     torch.cuda.synchronize()
     assert bool((Cm == 7.0).all())
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[3]])
+def test_the_three_small_net_paths_agree(shape):
+    """dun_fc_small_net_mode: 2 = one-launch forward / backward (persist.hip, the default), 1 = one column-owned launch
+    per block (smallnet.hip), 0 = the tiled GEMM path (what DUN_SMALLNET=0 selects).  Same entries, same buffers, three
+    kernel families: forward state and every gradient agree, and a whole fit step through the wrapper gives the same
+    returned numbers in each mode."""
+    from dun_amd import _lib
+    B, din, W, L, Oo, residual = shape
+    lib = _lib.lib()
+    prev = lib.dun_fc_small_net_mode(-1)
+    assert prev == 2                                              # nothing in the environment of the test run turns it off
+    outs = {}
+    try:
+        for mode in (2, 1, 0):
+            assert lib.dun_fc_small_net_mode(mode) in (0, 1, 2) and lib.dun_fc_small_net_mode(-1) == mode
+            model, x, be, g = make(*shape, seed=9)
+            model.train()
+            buf = be.fc_buffers(model, B, L, True)
+            buf.new_act(); buf.set_input(x)
+            be.fc_forward(buf)
+            dact = (torch.randn(L + 1, B, Oo, generator=g) / B).cuda()
+            buf.ensure_backward(); buf.set_dact(dact)
+            model.flat_grads.fill_(float("nan"))
+            be.fc_backward(buf)
+            torch.cuda.synchronize()
+            outs[mode] = dict(H=buf.H.clone(), act=buf.act.clone(), rm=model.running_mean.clone(), rv=model.running_var.clone(),
+                              nbt=model.num_batches_tracked.clone(), grads={k: v.clone() for k, v in model.stacked_grad.items()})
+        for mode in (1, 0):
+            a, b = outs[mode], outs[2]
+            close(a["H"], b["H"], 2e-4, "hidden states, mode %d" % mode)
+            close(a["act"], b["act"], 2e-4, "act_vec, mode %d" % mode)
+            close(a["rm"], b["rm"], 1e-4, "running mean, mode %d" % mode)
+            close(a["rv"], b["rv"], 1e-4, "running var, mode %d" % mode)
+            assert torch.equal(a["nbt"], b["nbt"]) and int(a["nbt"][0]) == 1
+            for k, v in b["grads"].items():
+                assert bool(torch.isfinite(a["grads"][k]).all()), (mode, k)
+                # (each mode's backward starts from its own forward: a ReLU input within rounding of 0 may fall on
+                #  either side, which moves single entries by O(1/B) -- see test_small_net_path_matches_tiled_path)
+                close(a["grads"][k], v, 2e-3, "gradient of %s, mode %d" % (k, mode))
+    finally:
+        lib.dun_fc_small_net_mode(prev)
+    assert lib.dun_fc_small_net_mode(-1) == prev
+
+
+def test_fit_step_is_the_same_in_every_small_net_mode():
+    from dun_amd import _lib
+    from tests.util import Case
+    from tests.test_wrappers_gpu import build_net
+    lib = _lib.lib()
+    prev = lib.dun_fc_small_net_mode(-1)
+    c = Case("c2_boston")
+    x, y = c.t("x"), c.y()
+    rets = {}
+    try:
+        for mode in (2, 1, 0):
+            lib.dun_fc_small_net_mode(mode)
+            net = build_net(c)
+            rets[mode] = np.array([net.fit(x, y) for _ in range(2)], dtype=np.float64)
+            assert np.allclose(rets[mode][0], c["fit/ret"][0], rtol=2e-5, atol=1e-6), (mode, rets[mode][0])
+    finally:
+        lib.dun_fc_small_net_mode(prev)
+    assert np.allclose(rets[1], rets[2], rtol=1e-4) and np.allclose(rets[0], rets[2], rtol=1e-4)
