@@ -379,13 +379,14 @@ def cpu_baseline(din, W, L, N_train, lr, momentum, wd, B_cpu):
     net.fit(x, y)  # warm-up (thread pools, allocator)
     t0 = time.time()
     steps = 0
-    while steps < 1 or (time.time() - t0 < 8.0 and steps < 20):
+    # a bounded sample: about 10 s of CPU work (two steps of the wide net, a few thousand of the UCI one), at least 1 step
+    while steps < 1 or (time.time() - t0 < 10.0 and steps < 20000):
         net.fit(x, y)
         steps += 1
     dt = (time.time() - t0) / steps
     return dict(value=B_cpu / dt, unit="samples/s", cores=threads, kind="port",
                 sample="%d DUN_VI.fit step(s) of the CPU oracle at batch %d (full workload batch: see config), "
-                       "%.2f s/step, throughput scaled per sample" % (steps, B_cpu, dt))
+                       "%.4g s/step, %.1f s of CPU work, throughput scaled per sample" % (steps, B_cpu, dt, dt * steps))
 
 
 def _claim_stdout():
