@@ -247,9 +247,19 @@ class ArchUncertResNet(ResNet):
         """Shared Linear over the stacked [D,B,K] exit features: one batched HIP contraction."""
         return _SharedHead.apply(torch.stack(feats, dim=0), self.output_block.weight, self.output_block.bias)
 
-    def fast_forward_impl(self, x, layer_probs, min_prob=1e-2):
+    def fast_forward_impl(self, x, layer_probs, min_prob=1e-2, device_mask=False):
         """Early-exit inference: exits whose posterior mass is <= min_prob are not evaluated (their rows stay 0).
-        One device->host copy of the D probabilities decides all exits (the reference syncs once per exit)."""
+        One device->host copy of the D probabilities decides all exits (the reference syncs once per exit,
+        src/DUN/stochastic_img_resnets.py:296).
+
+        device_mask=True: NO host synchronisation at all -- every exit is evaluated and the rows of the low-mass
+        exits are zeroed on the device by the same strict comparison.  Same act_vec (kept rows to fp32 rounding of a
+        differently shaped head contraction, exact zeros for the others), nothing skipped: for callers that cannot synchronise (a captured serving
+        step), where the decision which blocks to run cannot be taken on the host anyway."""
+        if device_mask:
+            act_vec = self._forward_impl(x)
+            keep = (layer_probs.detach() > min_prob).to(act_vec.device).view(-1, 1, 1)
+            return torch.where(keep, act_vec, torch.zeros_like(act_vec))
         keep = (layer_probs.detach() > min_prob).tolist()
         x = self.fwd_input_block(x)
         feats, kept = [], []

@@ -114,6 +114,11 @@ def run(dev):
             model.fast_forward_impl(x, q, min_prob=1e-2)
         skipped = [int(line.split()[-1]) for line in buf.getvalue().splitlines() if line.startswith("skipping layer")]
         assert skipped == [d + model.start_depth for d in ZERO_ROWS]      # the reference's message, per skipped block index
+        # the synchronisation-free form: all exits evaluated, low-mass rows zeroed on the device
+        fd = model.fast_forward_impl(x, q, min_prob=1e-2, device_mask=True).cpu().numpy()
+        assert [d for d in range(12) if not fd[d].any()] == ZERO_ROWS and rel_err(fd, fa) < 1e-6
+        for d in ZERO_ROWS:
+            assert np.array_equal(fd[d], np.zeros_like(fd[d]))
         pm.current_posterior = q
         assert rel_err(quiet(net.fast_predict, x).cpu(), c["fast/pred"]) < TOL
         # min_prob is a strict threshold (layer_probs > min_prob): mass exactly at it is skipped
