@@ -12,7 +12,11 @@ pytestmark = pytest.mark.gpu
 # (B, din, W, L, O, residual): toy / UCI shapes, padded LDS stride (W/4 even), several row chunks, ragged batches,
 # 4-float input rows (vector dW_in path), the narrowest width
 SHAPES = [(300, 1, 100, 3, 1, True), (512, 13, 100, 10, 1, True), (512, 9, 128, 2, 3, True),
-          (1000, 8, 64, 3, 1, False), (37, 5, 4, 2, 2, True), (2000, 13, 40, 2, 1, True), (256, 16, 100, 1, 1, True)]
+          (1000, 8, 64, 3, 1, False), (37, 5, 4, 2, 2, True), (2000, 13, 40, 2, 1, True), (256, 16, 100, 1, 1, True),
+          # the one-launch kernels' corners: 8 column tiles, the widest batch (128 workgroups), an input layer too wide for
+          # the LDS stage (din > 32), three rows (with two, BatchNorm's input gradient is pure cancellation noise), a ragged last workgroup, the narrowest width, a single column tile short of full
+          (2048, 40, 128, 2, 1, True), (3, 3, 8, 2, 1, True), (17, 33, 28, 3, 1, False), (1029, 7, 112, 2, 1, True),
+          (640, 64, 4, 3, 1, True), (48, 1, 124, 12, 1, True)]
 
 
 def make(B, din, W, L, Oo, residual, seed=0):
