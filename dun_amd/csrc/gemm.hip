@@ -883,14 +883,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
     DUN_WAIT_LGKMCNT0();
 
     int cur = 0, nxt = WSTAGE, iss = 2 * WSTAGE;  // float offsets of the stages of half j, j+1, j+2 (a ring of three)
+// timing experiments only (results are wrong): what the mid-step barrier / the operand DMA / the fragment reads cost
+#ifdef DUN_EXP_NODMA
+#define DUN_EXP_DMA false
+#else
+#define DUN_EXP_DMA true
+#endif
+#ifdef DUN_EXP_NOLDS
+#define DUN_EXP_LDS false
+#else
+#define DUN_EXP_LDS true
+#endif
+#ifdef DUN_EXP_NOBAR
+#define DUN_WIDE_BARRIER() do { } while (0)
+#else
+#define DUN_WIDE_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 #define DUN_WIDE_STEP(J, NEXT, INFLIGHT, ISSUE)                                                                                 \
     do {                                                                                                               \
         const float* a_s = smem + cur;                                                                                 \
         const float* b_s = a_s + WA_HALF;                                                                              \
+        if (DUN_EXP_LDS) {                                                                                             \
         _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                               \
             read_frag_w<A_KC, BM>(a_s, wr * 64 + mi * 32 + li, 1, h, fa[1][mi]);                                       \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                               \
             read_frag_w<B_KC, WBN>(b_s, wc * 128 + ni * 32 + li, 1, h, fb[1][ni]);                                     \
+        }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
             _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
@@ -900,17 +918,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
         DUN_WAIT_LGKMCNT0();                                                                                           \
         if (NEXT) {                                                                                                    \
             if (INFLIGHT) DUN_WAIT_VMCNT(6); else DUN_WAIT_VMCNT(0); /* half J+1 landed, J+2 may stay in flight */     \
-            __builtin_amdgcn_s_barrier();                                                                              \
-            if (ISSUE) { /* every wave has read the last fragment of half J: its stage takes half J+3 */             \
+            DUN_WIDE_BARRIER();                                                                                        \
+            if (ISSUE && DUN_EXP_DMA) { /* every wave has read the last fragment of half J: its stage takes half J+3 */ \
                 dA.issue(kbeg + ((J) + 3) * HK, smem + cur, wave);                                                     \
                 dB.issue(kbeg + ((J) + 3) * HK, smem + cur + WA_HALF, wave);                                           \
             }                                                                                                          \
             const float* a_n = smem + nxt;                                                                             \
             const float* b_n = a_n + WA_HALF;                                                                          \
+            if (DUN_EXP_LDS) {                                                                                         \
             _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
                 read_frag_w<A_KC, BM>(a_n, wr * 64 + mi * 32 + li, 0, h, fa[0][mi]);                                   \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                           \
                 read_frag_w<B_KC, WBN>(b_n, wc * 128 + ni * 32 + li, 0, h, fb[0][ni]);                                 \
+            }                                                                                                          \
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
