@@ -174,6 +174,9 @@ def gemm_kernel_name(M, N, K, a_kc, b_kc, plain_few_tiles=False):
     """Which GEMM kernel the library dispatches for this shape (dun_amd/csrc/gemm.hip: gemm_f32)."""
     small = ((M + 127) // 128) * ((N + 127) // 128) < 128
     if not small and M % 128 == 0 and N % 128 == 0 and K % 32 == 0:
+        from dun_amd import _lib
+        if _lib.lib().dun_gemm_precision(-1) == 1:
+            return "gemm_bf16x3_kernel<A_KC=%d,B_KC=%d> (EXPLORATORY: 6 bf16 MFMA products per fp32 product)" % (a_kc, b_kc)
         wide = N % 256 == 0 and (M // 128) * (N // 256) >= 512 and not plain_few_tiles and (a_kc or not b_kc)
         if wide:
             return "gemm_f32_wide_kernel<A_KC=%d,B_KC=%d> (128x256 tiles)" % (a_kc, b_kc)
@@ -387,6 +390,19 @@ def cpu_baseline(din, W, L, N_train, lr, momentum, wd, B_cpu):
     return dict(value=B_cpu / dt, unit="samples/s", cores=threads, kind="port",
                 sample="%d DUN_VI.fit step(s) of the CPU oracle at batch %d (full workload batch: see config), "
                        "%.4g s/step, %.1f s of CPU work, throughput scaled per sample" % (steps, B_cpu, dt, dt * steps))
+
+
+def label_exploratory(result):
+    """EXPLORATORY switch (DUN_GEMM_BF16X3=1 / dun_gemm_precision(1)): never the headline, labelled as what it is."""
+    from dun_amd import _lib
+    if _lib.lib().dun_gemm_precision(-1) != 1:
+        return
+    result["dtype"] = ("f32 operands split into 3 bf16 digits, 6 bf16 MFMA products, f32 accumulate "
+                       "(EXPLORATORY switch, not the measured path)")
+    result["metric"] = "EXPLORATORY (bf16x3 GEMMs): " + result["metric"]
+    if "roofline" in result:
+        result["roofline"]["note"] = ("exploratory bf16x3 kernel: `achieved` counts the fp32-equivalent 2*M*N*K flop, "
+                                      "`peak` stays the exact-fp32 MFMA peak for scale -- not a roofline claim")
 
 
 def _claim_stdout():
@@ -611,13 +627,16 @@ def run_rank(args):
         if not bool(torch.isfinite(first).all()):
             raise SystemExit("bench.py: non-finite predictions")
         if rank == 0:
-            print(json.dumps({
+            line = {
                 "metric": "DUN predict samples/sec", "value": B * args.steps / dt, "unit": "samples/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "%s: predict, global batch %d (%d rows/GPU)" % (args.workload, B, B_local),
                            "parallelism": "dp%d batch-sharded (no collective: eval-mode BatchNorm)" % world,
-                           "distributed": dist_fields()}}), file=json_out, flush=True)
+                           "distributed": dist_fields()}}
+            if not cpu:
+                label_exploratory(line)
+            print(json.dumps(line), file=json_out, flush=True)
         if dist_on:
             dist.barrier()
             dist.destroy_process_group()
@@ -725,6 +744,8 @@ def run_rank(args):
                 {"bound": "hbm", "achieved": v["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": v["gbs"] / HBM_PEAK_GBS, "ms_per_launch": v["ms"]})
             for k, v in kr.items() if k != "gemm_fwd"}
+    if rank == 0 and not cpu:
+        label_exploratory(result)
     if rank == 0 and world == 1 and not cpu and args.workload == "c3_wide" and not args.no_secondary:
         result["secondary"] = secondary_c2()
     if rank == 0 and not args.no_cpu_baseline and world == 1:

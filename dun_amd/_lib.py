@@ -18,7 +18,7 @@ RES_OBJECTIVE, RES_E_LOGLIKE, RES_KL, RES_LOG_MARG, RES_DLOG_STD, RES_HEADER = 0
 EXPORTS = [
     "dun_abi_version", "dun_last_error", "dun_ll_num_partials", "dun_ll_gauss", "dun_ll_softmax", "dun_ll_reduce",
     "dun_depth_finalize", "dun_depth_finalize_partials", "dun_elbo_gauss_workspace_doubles", "dun_elbo_gauss",
-    "dun_static_init", "dun_elbo_gauss_static_max_doubles", "dun_elbo_gauss_static", "dun_predict_gauss", "dun_predict_softmax", "dun_predict_num_partials", "dun_gemm_f32", "dun_gemm_colstat_tiles",
+    "dun_static_init", "dun_elbo_gauss_static_max_doubles", "dun_elbo_gauss_static", "dun_predict_gauss", "dun_predict_softmax", "dun_predict_num_partials", "dun_gemm_f32", "dun_gemm_colstat_tiles", "dun_gemm_precision",
     "dun_fc_workspace_floats", "dun_fc_obj_num_partials", "dun_fc_head_is_fused", "dun_fc_forward", "dun_fc_backward", "dun_fc_input_layer", "dun_fc_block_linear",
     "dun_fc_block_norm", "dun_fc_block_apply", "dun_fc_head", "dun_fc_head_depth", "dun_fc_bwd_begin", "dun_fc_bwd_block_reduce", "dun_fc_bwd_block_apply", "dun_fc_bwd_block_dx", "dun_fc_bwd_block_dw",
     "dun_fc_bwd_end", "dun_head_forward", "dun_head_backward_workspace_floats", "dun_head_backward", "dun_sgd_step",
@@ -106,6 +106,7 @@ def _declare(lib):
         "dun_predict_gauss": (i, [vp, vp, i, i, vp, vp, vp, vp, vp, vp, vp]),
         "dun_predict_softmax": (i, [vp, vp, i, i, i, vp, vp, vp, vp, vp]),
         "dun_gemm_f32": (i, [C.POINTER(GemmDesc), vp]),
+        "dun_gemm_precision": (i, [i]),
         "dun_gemm_colstat_tiles": (i, [i, i]),
         "dun_fc_workspace_floats": (sz, [i, i, i, i, i]),
         "dun_fc_obj_num_partials": (i, [i, i]),

@@ -61,6 +61,7 @@ struct GemmP {
     const float* ev_shift;
     const float* ev_hw;
     float* ev_hpart;
+    int x3;       // exploratory bf16 x 3 kernel (gemm_precision() == 1)
 };
 
 // ---- global -> register staging of one operand tile: 4 x float4 per thread ----
@@ -780,6 +781,202 @@ extern "C" int dun_debug_gemm_timing(void* buf) {
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
+// EXPLORATORY, off by default (dun_gemm_precision(1) / DUN_GEMM_BF16X3=1), never the measured headline: the same
+// 128 x 128 LDS-DMA pipeline with each fp32 operand element split EXACTLY into three bf16 digits in registers
+// (x = hi + mid + lo: 8 + 8 + 8 mantissa bits, by truncation, so nothing is lost in the split) and the product taken
+// as six bf16 MFMAs with fp32 accumulation -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped terms
+// (mid*lo, lo*mid, lo*lo) are below 2^-23 of |a*b| per element product.  bf16 MFMA runs at 16x the fp32 MFMA rate,
+// so six products are 0.375 of the matrix-pipe time; the split costs ~5.5 vector-ALU operations per operand element
+// per wave, which the other wave of the SIMD runs under the MFMAs.  HBM and LDS traffic are those of the fp32 kernel
+// (operands travel as fp32).  Any assignment of k to (lane half, element) is valid for the MFMA as long as A and B use
+// the same one: a lane's eight k values are the fp32 kernel's fragments of k groups 0 and 1.
+// ---------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// planes of a fragment: [0] = hi, [1] = mid, [2] = lo; 8 k values per lane as packed bf16 pairs
+__device__ __forceinline__ void x3_split(const float (&f0)[4], const float (&f1)[4], u32x4 (&o)[3]) {
+    float x[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+    float r[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float hi = __uint_as_float(__float_as_uint(x[i]) & 0xffff0000u);
+        r[i] = x[i] - hi;                                                      // exact: the low 16 mantissa bits
+        const float mid = __uint_as_float(__float_as_uint(r[i]) & 0xffff0000u);
+        q[i] = r[i] - mid;                                                     // exact: <= 8 significant bits left
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // (element 2i in the low half, 2i+1 in the high half: top 16 bits of each)
+        o[0][i] = __builtin_amdgcn_perm(__float_as_uint(x[2 * i + 1]), __float_as_uint(x[2 * i]), 0x07060302u);
+        o[1][i] = __builtin_amdgcn_perm(__float_as_uint(r[2 * i + 1]), __float_as_uint(r[2 * i]), 0x07060302u);
+        o[2][i] = __builtin_amdgcn_perm(__float_as_uint(q[2 * i + 1]), __float_as_uint(q[2 * i]), 0x07060302u);
+    }
+}
+
+#define DUN_X3_MFMA(a, b, c) \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+// the four accumulators of a wave with plane PA of A against plane PB of B
+#define DUN_X3_PRODUCT(XA, XB, PA, PB)                                                                                 \
+    do {                                                                                                               \
+        DUN_X3_MFMA(XA[0][PA], XB[0][PB], acc[0][0]); DUN_X3_MFMA(XA[0][PA], XB[1][PB], acc[0][1]);                    \
+        DUN_X3_MFMA(XA[1][PA], XB[0][PB], acc[1][0]); DUN_X3_MFMA(XA[1][PA], XB[1][PB], acc[1][1]);                    \
+    } while (0)
+
+__device__ __forceinline__ void x3_wait_groups(int n) {  // at most n DMA groups (4 loads each) of this wave in flight
+    if (n >= 3) DUN_WAIT_VMCNT(12);
+    else if (n == 2) DUN_WAIT_VMCNT(8);
+    else if (n == 1) DUN_WAIT_VMCNT(4);
+    else DUN_WAIT_VMCNT(0);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * STAGE];
+    const int nwg = p.gridM * p.gridN;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.gridN, bn = bid % p.gridN;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+    seed_acc<true, 2>(p, acc, m0, n0, wr, wc, li, h);
+
+    const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * (p.K / p.ksplit) : 0;
+    const int nh = (p.ksplit > 1 ? p.K / p.ksplit : p.K) / HK;  // >= 2
+    const DmaOp dA = dma_setup<A_KC>(p.A, p.lda, m0, p.M, p.K, wave, lane);
+    const DmaOp dB = dma_setup<B_KC>(p.B, p.ldb, n0, p.N, p.K, wave, lane);
+    // Software pipeline over half tiles (16 k): during step J the wave issues the MFMAs of half J from bf16 registers,
+    // splits the fp32 fragments of half J+1 (read from LDS during step J-1) under them, and reads the fragments of
+    // half J+2; the DMA runs three halves ahead of the reads through a ring of four stages.
+    const int npre = nh < 4 ? nh : 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < nh) {
+            dma_half(dA, kbeg + j * HK, smem + j * STAGE, wave);
+            dma_half(dB, kbeg + j * HK, smem + j * STAGE + HALF_TILE, wave);
+        }
+    }
+    asm volatile("" ::"s"(p.C), "s"(p.bias), "s"(p.R), "s"(p.U), "s"(p.V), "s"(p.colstats), "s"(p.M), "s"(p.N),
+                 "s"(p.ldc), "s"(p.ldr), "s"(p.O), "s"(p.ldv), "s"(p.relu), "s"(p.gridM), "s"(p.rinit), "s"(p.bnz),
+                 "s"(p.bn_mean), "s"(p.bn_rstd), "s"(p.bnstats), "s"(p.ldz));
+
+    float fa[2][2][4], fb[2][2][4];  // fp32 fragments [k group][tile][e] of the half being split next
+#define DUN_X3_READ(ST)                                                                                                \
+    do {                                                                                                               \
+        const float* a_s = smem + (ST) * STAGE;                                                                        \
+        const float* b_s = a_s + HALF_TILE;                                                                            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+                read_frag_half<A_KC>(a_s, wr * 64 + mi * 32 + li, t, h, fa[t][mi]);                                    \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                           \
+                read_frag_half<B_KC>(b_s, wc * 64 + ni * 32 + li, t, h, fb[t][ni]);                                    \
+        }                                                                                                              \
+    } while (0)
+#define DUN_X3_SPLIT(XA, XB)                                                                                           \
+    do {                                                                                                               \
+        x3_split(fa[0][0], fa[1][0], XA[0]); x3_split(fa[0][1], fa[1][1], XA[1]);                                      \
+        x3_split(fb[0][0], fb[1][0], XB[0]); x3_split(fb[0][1], fb[1][1], XB[1]);                                      \
+    } while (0)
+
+    u32x4 x0a[2][3], x0b[2][3], x1a[2][3], x1b[2][3];  // two sets of bf16 operands: [tile][plane]
+    x3_wait_groups(npre - 1);  // half 0 landed ...
+    __builtin_amdgcn_s_barrier();  // ... everyone's pieces
+    DUN_X3_READ(0);
+    DUN_WAIT_LGKMCNT0();
+    DUN_X3_SPLIT(x0a, x0b);
+    x3_wait_groups(npre - 2);  // half 1 (nh >= 2)
+    __builtin_amdgcn_s_barrier();  // (and everyone is past reading half 0: its stage takes half 4, as "step -1" would)
+    if (nh > 4) {
+        dma_half(dA, kbeg + 4 * HK, smem, wave);
+        dma_half(dB, kbeg + 4 * HK, smem + HALF_TILE, wave);
+    }
+    DUN_X3_READ(1);
+
+    // (timing experiments, results wrong: -DDUN_X3_NOSPLIT / _NODMA / _NOREAD take a piece out of the steady state)
+#ifdef DUN_X3_NOSPLIT
+#define DUN_X3E_SPLIT false
+#else
+#define DUN_X3E_SPLIT true
+#endif
+#ifdef DUN_X3_NODMA
+#define DUN_X3E_DMA false
+#else
+#define DUN_X3E_DMA true
+#endif
+#ifdef DUN_X3_NOPATTERN
+#define DUN_X3E_PATTERN false
+#else
+#define DUN_X3E_PATTERN true
+#endif
+#ifdef DUN_X3_NOREAD
+#define DUN_X3E_READ false
+#else
+#define DUN_X3E_READ true
+#endif
+    // FAST: steady state (halves J+1 .. J+5 exist), compile-time shape and a forced 1 MFMA : 15 vector-ALU issue pattern
+#define DUN_X3_STEP(J, CA, CB, NA, NB, FAST)                                                                           \
+    do {                                                                                                               \
+        DUN_WAIT_LGKMCNT0(); /* the fp32 fragments of half J+1 are in registers */                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if ((FAST && DUN_X3E_SPLIT) || (!FAST && (J) + 1 < nh)) DUN_X3_SPLIT(NA, NB);                                  \
+        DUN_X3_PRODUCT(CA, CB, 0, 2); DUN_X3_PRODUCT(CA, CB, 2, 0); DUN_X3_PRODUCT(CA, CB, 1, 1); /* small terms */    \
+        if (FAST && DUN_X3E_PATTERN) {                                                                                 \
+            _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                                        \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+                __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);                                                    \
+            }                                                                                                          \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (FAST || (J) + 2 < nh) {                                                                                    \
+            if (FAST) DUN_WAIT_VMCNT(8); else x3_wait_groups((nh - 1 < (J) + 4 ? nh - 1 : (J) + 4) - ((J) + 2));       \
+            __builtin_amdgcn_s_barrier(); /* half J+2 landed for everyone; everyone is past reading half J+1 */       \
+            if ((FAST && DUN_X3E_DMA) || (!FAST && (J) + 5 < nh)) {                                                    \
+                float* st = smem + (((J) + 1) & 3) * STAGE;                                                            \
+                dma_half(dA, kbeg + ((J) + 5) * HK, st, wave);                                                         \
+                dma_half(dB, kbeg + ((J) + 5) * HK, st + HALF_TILE, wave);                                             \
+            }                                                                                                          \
+            if (!FAST || DUN_X3E_READ) DUN_X3_READ(((J) + 2) & 3);                                                     \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_X3_PRODUCT(CA, CB, 0, 1); DUN_X3_PRODUCT(CA, CB, 1, 0); DUN_X3_PRODUCT(CA, CB, 0, 0); /* leading last */   \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    } while (0)
+
+    int j = 0;
+    for (; j + 6 < nh; j += 2) {
+        DUN_X3_STEP(j, x0a, x0b, x1a, x1b, true);
+        DUN_X3_STEP(j + 1, x1a, x1b, x0a, x0b, true);
+    }
+    while (j < nh) {  // the last (up to six) halves: run-time shape
+        DUN_X3_STEP(j, x0a, x0b, x1a, x1b, false);
+        if (++j >= nh) break;
+        DUN_X3_STEP(j, x1a, x1b, x0a, x0b, false);
+        ++j;
+    }
+#undef DUN_X3_STEP
+#undef DUN_X3_SPLIT
+#undef DUN_X3_READ
+    __syncthreads();
+    if (p.ksplit > 1) {
+        GemmP q = p;
+        q.C = p.part + (size_t)blockIdx.y * p.M * p.N;
+        q.ldc = p.N;
+        q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr; q.bnz = nullptr;
+        gemm_epilogue<true, 2>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    } else if (p.ev_scale != nullptr) {
+        gemm_epilogue_eval<2, 2>(p, acc, smem, m0, n0, bn, tid, wr, wc, li, h);
+    } else {
+        gemm_epilogue<true, 2>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Wide variant: 128 x 256 tiles (a wave owns 64 x 128 = 2 x 4 MFMA accumulators), three 16-deep stages of 24 KiB
 // (72 KiB: still two workgroups per CU).  Per barrier a wave now issues 64 MFMAs instead of 32 and reads 12 fragment
 // vectors instead of 8, and a tile's prologue / store bubble is paid once per 2x the work.  Three stages carry the same
@@ -991,9 +1188,30 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict
     }
 }
 
+// 0 = exact fp32 MFMA (the product), 1 = the exploratory bf16 x 3 split on LDS-DMA-eligible problems; -1: environment
+static int g_gemm_precision = -1;
+int gemm_precision() {
+    if (g_gemm_precision < 0) {
+        const char* e = getenv("DUN_GEMM_BF16X3");
+        g_gemm_precision = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_gemm_precision;
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream_t s) {
     const int grid = p.gridM * p.gridN;
+    if (dma && p.x3) {
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+        if (p.ksplit > 1) {
+            const size_t n4 = (size_t)p.M * p.N / 4;
+            size_t blocks = (n4 + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
+        }
+        DUN_LAUNCH_CHECK();
+        return DUN_OK;
+    }
     if (p.wide) {
         hipLaunchKernelGGL((gemm_f32_wide_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
         if (p.ksplit > 1) {
@@ -1039,6 +1257,7 @@ static bool small_problem(int M, int N) {
 // row tiles of an M x N problem = rows of the colstats partial matrix
 int gemm_colstat_tiles(int M, int N) { return ceil_div(M, small_problem(M, N) ? 64 : BM); }
 
+int gemm_precision();
 // measurement window of dun_gemm_profile_begin / _end (below)
 struct GemmProfSlot {
     hipEvent_t a, b;
@@ -1151,14 +1370,15 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     // 128 x 256 tiles where they fill the chip without split-K (the trunk's forward and dX GEMMs): the per-tile
     // prologue / store bubble is paid once per twice the work.  (A residual must seed the accumulators there, or be added
     // by the inference epilogue, which gathers it chunk by chunk.)
-    if (dma && p.ksplit == 1 && d->N % WBN == 0 &&
+    p.x3 = (dma && gemm_precision() == 1) ? 1 : 0;
+    if (!p.x3 && dma && p.ksplit == 1 && d->N % WBN == 0 &&
         (long long)p.gridM * (d->N / WBN) >= 512 && d->K >= 64 && (!d->R || p.rinit || d->ev_scale) &&
         (!d->U || (d->O == 1 && !d->bias && !d->relu)) &&
         (d->a_kcontig || !d->b_kcontig)) {  // (the <M-contiguous, K-contiguous> instantiation spills: none of the trunk's GEMMs)
         p.wide = 1;
         p.gridN = d->N / WBN;
     }
-    GemmProfSlot* slot = gemm_profile_open(d, p.wide ? 2 : (dma ? 1 : 0), p.ksplit, s);
+    GemmProfSlot* slot = gemm_profile_open(d, p.x3 ? 3 : (p.wide ? 2 : (dma ? 1 : 0)), p.ksplit, s);
     int rc;
     if (d->a_kcontig)
         rc = d->b_kcontig ? launch_gemm<true, true>(p, vec, dma, small, s) : launch_gemm<true, false>(p, vec, dma, small, s);
@@ -1171,6 +1391,12 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
 }  // namespace dun
 
 extern "C" int dun_gemm_colstat_tiles(int M, int N) { return dun::gemm_colstat_tiles(M, N); }
+
+extern "C" int dun_gemm_precision(int mode) {
+    const int prev = dun::gemm_precision();
+    if (mode == 0 || mode == 1) dun::g_gemm_precision = mode;
+    return prev;
+}
 
 extern "C" int dun_gemm_f32(const dun_gemm_desc* desc, dun_stream_t stream) {
     return dun::gemm_f32(desc, static_cast<hipStream_t>(stream));

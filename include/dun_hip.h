@@ -217,6 +217,13 @@ int dun_gemm_profile_end(dun_gemm_profile_rec* out /* host */, int cap);
  * the chip with 128x128 tiles).  No reference counterpart: sizing helper for `colstats`. */
 int dun_gemm_colstat_tiles(int M, int N);
 
+/* EXPLORATORY, off by default, no counterpart in the reference and never the measured path: mode 1 runs the problems
+ * that qualify for the 128 x 128 LDS-DMA kernel with every fp32 operand element split exactly into three bf16 digits
+ * and the product taken as six bf16 MFMAs with fp32 accumulation (terms below 2^-23 of |a b| dropped); mode 0 (the
+ * default, and what every number in DESIGN.md is measured with) is exact fp32 MFMA.  Returns the previous mode;
+ * any other argument only queries.  Process-wide; DUN_GEMM_BF16X3=1 in the environment selects mode 1 at first use. */
+int dun_gemm_precision(int mode);
+
 /* ------------------------------------------------------------------------------------------------------
  * Residual-MLP trunk ("forward_get_acts"): arq_uncert_fc_resnet.forward / arq_uncert_fc_MLP
  * (src/DUN/stochastic_fc_models.py:62-80) with bern_MLPBlock[_nores] (src/DUN/layers.py:33-53),
