@@ -1175,6 +1175,146 @@ template __global__ void gemm_f32_wide_kernel<true, false>(const GemmP);
 template __global__ void gemm_f32_wide_kernel<false, true>(const GemmP);
 template __global__ void gemm_f32_wide_kernel<false, false>(const GemmP);
 
+// The bf16 x 3 kernel on 128 x 256 tiles (wave tile 64 x 128): the split of the A fragments serves four accumulator
+// columns instead of two and each fragment read twice the MFMAs -- per MFMA a quarter less vector-ALU work, 5/8 fewer LDS
+// reads, a quarter fewer DMA pieces, which is what this issue-bound kernel is short of.  128 accumulator registers
+// leave room for ONE set of bf16 operands, B two columns at a time: split A and B[0..1] -> 24 MFMAs -> split B[2..3] ->
+// barrier, DMA, fragment reads of the next half -> 24 MFMAs.  Three 24 KiB stages like gemm_f32_wide_kernel.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) float smem[3 * WSTAGE];
+    const int nwg = p.gridM * p.gridN;  // gridN counts 256-column tiles
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.gridN, bn = bid % p.gridN;
+    const int m0 = bm * BM, n0 = bn * WBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][4];
+    seed_acc<true, 2, 4>(p, acc, m0, n0, wr, wc, li, h);
+
+    const int nh = p.K / HK;  // >= 4 (host)
+    DmaOpW<A_KC, BM> dA;
+    DmaOpW<B_KC, WBN> dB;
+    dA.setup(p.A, p.lda, m0, p.M, p.K, wave, lane);
+    dB.setup(p.B, p.ldb, n0, p.N, p.K, wave, lane);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        dA.issue(j * HK, smem + j * WSTAGE, wave);
+        dB.issue(j * HK, smem + j * WSTAGE + WA_HALF, wave);
+    }
+    DUN_WAIT_VMCNT(12);  // half 0 landed (6 loads per half and wave)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::"s"(p.C), "s"(p.bias), "s"(p.R), "s"(p.U), "s"(p.V), "s"(p.colstats), "s"(p.M), "s"(p.N),
+                 "s"(p.ldc), "s"(p.ldr), "s"(p.O), "s"(p.ldv), "s"(p.relu), "s"(p.gridM), "s"(p.rinit), "s"(p.bnz),
+                 "s"(p.bn_mean), "s"(p.bn_rstd), "s"(p.bnstats), "s"(p.ldz));
+
+    float fa[2][2][4], fb[2][4][4];  // fp32 fragments [k group][tile][e]
+#define DUN_X3W_READ(OFF)                                                                                              \
+    do {                                                                                                               \
+        const float* a_s = smem + (OFF);                                                                               \
+        const float* b_s = a_s + WA_HALF;                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
+                read_frag_w<A_KC, BM>(a_s, wr * 64 + mi * 32 + li, t, h, fa[t][mi]);                                   \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                           \
+                read_frag_w<B_KC, WBN>(b_s, wc * 128 + ni * 32 + li, t, h, fb[t][ni]);                                 \
+        }                                                                                                              \
+    } while (0)
+// the two accumulators of column NI (operand set XBI of B) against all six plane pairs, small terms first
+#define DUN_X3W_COL(NI, XBI)                                                                                           \
+    do {                                                                                                               \
+        DUN_X3_MFMA(xa[0][0], XBI[2], acc[0][NI]); DUN_X3_MFMA(xa[1][0], XBI[2], acc[1][NI]);                          \
+        DUN_X3_MFMA(xa[0][2], XBI[0], acc[0][NI]); DUN_X3_MFMA(xa[1][2], XBI[0], acc[1][NI]);                          \
+        DUN_X3_MFMA(xa[0][1], XBI[1], acc[0][NI]); DUN_X3_MFMA(xa[1][1], XBI[1], acc[1][NI]);                          \
+        DUN_X3_MFMA(xa[0][0], XBI[1], acc[0][NI]); DUN_X3_MFMA(xa[1][0], XBI[1], acc[1][NI]);                          \
+        DUN_X3_MFMA(xa[0][1], XBI[0], acc[0][NI]); DUN_X3_MFMA(xa[1][1], XBI[0], acc[1][NI]);                          \
+        DUN_X3_MFMA(xa[0][0], XBI[0], acc[0][NI]); DUN_X3_MFMA(xa[1][0], XBI[0], acc[1][NI]);                          \
+    } while (0)
+// issue pattern of a column's 12 MFMAs with one split (44 vector-ALU operations) underneath
+#define DUN_X3W_PATTERN()                                                                                              \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                         \
+        }                                                                                                              \
+    } while (0)
+    DUN_X3W_READ(0);
+
+    u32x4 xa[2][3], xb[2][3];
+    int cur = 0, nxt = WSTAGE, iss = 2 * WSTAGE;  // stages of half j, j+1, j+2
+#define DUN_X3W_STEP(J, NEXT, INFLIGHT, ISSUE)                                                                         \
+    do {                                                                                                               \
+        DUN_WAIT_LGKMCNT0(); /* fp32 fragments of half J in registers */                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        /* (one split at a time: interleaved, their temporaries spill next to 128 accumulators) */                    \
+        x3_split(fa[0][0], fa[1][0], xa[0]); __builtin_amdgcn_sched_barrier(0);                                        \
+        x3_split(fa[0][1], fa[1][1], xa[1]); __builtin_amdgcn_sched_barrier(0);                                        \
+        x3_split(fb[0][0], fb[1][0], xb[0]); __builtin_amdgcn_sched_barrier(0);                                        \
+        /* column 0 with the split of column 1 under it, column 1 with that of column 2 (into the operand registers  \
+           column 0 has just been issued from), column 2 with that of column 3.  (Measured and not kept: the fragment  \
+           reads moved up in front of column 2 and the next half's column 0 split under column 3 -- spills in the     \
+           loop, 2.44 -> 2.49 ms.) */                                                                                 \
+        x3_split(fb[0][1], fb[1][1], xb[1]); DUN_X3W_COL(0, xb[0]); DUN_X3W_PATTERN();                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        x3_split(fb[0][2], fb[1][2], xb[0]); DUN_X3W_COL(1, xb[1]); DUN_X3W_PATTERN();                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        x3_split(fb[0][3], fb[1][3], xb[1]); DUN_X3W_COL(2, xb[0]); DUN_X3W_PATTERN();                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (NEXT) {                                                                                                    \
+            if (INFLIGHT) DUN_WAIT_VMCNT(6); else DUN_WAIT_VMCNT(0); /* half J+1 landed, J+2 may stay in flight */     \
+            __builtin_amdgcn_s_barrier();                            /* everyone has read half J: its stage is free */ \
+            if (ISSUE) {                                                                                               \
+                dA.issue(((J) + 3) * HK, smem + cur, wave);                                                            \
+                dB.issue(((J) + 3) * HK, smem + cur + WA_HALF, wave);                                                  \
+            }                                                                                                          \
+            DUN_X3W_READ(nxt);                                                                                         \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_X3W_COL(3, xb[1]);                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        { const int t_ = cur; cur = nxt; nxt = iss; iss = t_; }                                                        \
+    } while (0)
+
+    int j = 0;
+    for (; j + 3 < nh; ++j) DUN_X3W_STEP(j, true, true, true);
+    { DUN_X3W_STEP(j, true, true, false); ++j; }
+    { DUN_X3W_STEP(j, true, false, false); ++j; }
+    DUN_X3W_STEP(j, false, false, false);
+#undef DUN_X3W_STEP
+#undef DUN_X3W_PATTERN
+#undef DUN_X3W_COL
+#undef DUN_X3W_READ
+
+    if (p.U != nullptr) {  // rank-1 term of the head as one more exact-fp32 MFMA step (see gemm_f32_wide_kernel)
+        float ua[2], vb[4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) ua[mi] = h == 0 ? p.U[m0 + wr * 64 + mi * 32 + li] : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) vb[ni] = h == 0 ? p.V[n0 + wc * 128 + ni * 32 + li] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[mi], vb[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+    if (p.ev_scale != nullptr)
+        gemm_epilogue_eval<2, 4>(p, acc, smem, m0, n0, bn, tid, wr, wc, li, h);
+    else
+        gemm_epilogue<true, 2, 4, true>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+}
+
+template __global__ void gemm_bf16x3_wide_kernel<true, true>(const GemmP);
+template __global__ void gemm_bf16x3_wide_kernel<true, false>(const GemmP);
+template __global__ void gemm_bf16x3_wide_kernel<false, true>(const GemmP);
+template __global__ void gemm_bf16x3_wide_kernel<false, false>(const GemmP);
+
 // C[m][n] = part[0][m][n] + part[1][m][n] + ... (fixed order: reproducible)
 __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ part, int ksplit, int M, int N,
                                                          float* __restrict__ C, int ldc) {
@@ -1201,6 +1341,11 @@ int gemm_precision() {
 template <bool A_KC, bool B_KC>
 static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream_t s) {
     const int grid = p.gridM * p.gridN;
+    if (dma && p.x3 && p.wide) {
+        hipLaunchKernelGGL((gemm_bf16x3_wide_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
+        DUN_LAUNCH_CHECK();
+        return DUN_OK;
+    }
     if (dma && p.x3) {
         hipLaunchKernelGGL((gemm_bf16x3_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
         if (p.ksplit > 1) {
@@ -1371,7 +1516,7 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     // prologue / store bubble is paid once per twice the work.  (A residual must seed the accumulators there, or be added
     // by the inference epilogue, which gathers it chunk by chunk.)
     p.x3 = (dma && gemm_precision() == 1) ? 1 : 0;
-    if (!p.x3 && dma && p.ksplit == 1 && d->N % WBN == 0 &&
+    if (dma && p.ksplit == 1 && d->N % WBN == 0 &&
         (long long)p.gridM * (d->N / WBN) >= 512 && d->K >= 64 && (!d->R || p.rinit || d->ev_scale) &&
         (!d->U || (d->O == 1 && !d->bias && !d->relu)) &&
         (d->a_kcontig || !d->b_kcontig)) {  // (the <M-contiguous, K-contiguous> instantiation spills: none of the trunk's GEMMs)

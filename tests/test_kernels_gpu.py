@@ -529,8 +529,7 @@ def test_exploratory_bf16x3_gemm_meets_the_fp32_tolerance(be, a_kc, b_kc):
     accumulators, split-K)."""
     from dun_amd import _lib
     lib = _lib.lib()
-    prev = lib.dun_gemm_precision(-1)
-    assert prev == 0
+    prev = lib.dun_gemm_precision(-1)   # (0 unless the run itself has DUN_GEMM_BF16X3=1 in its environment)
     try:
         g = torch.Generator().manual_seed(11)
         for (M, N, K) in ((4096, 512, 256), (2048, 2048, 2048), (8192, 2048, 96)):
@@ -566,4 +565,4 @@ def test_exploratory_bf16x3_gemm_meets_the_fp32_tolerance(be, a_kc, b_kc):
         assert bool(torch.isfinite(out).all()) and float((out.cpu().double() - want).abs().max()) < 1e-6
     finally:
         lib.dun_gemm_precision(prev)
-    assert lib.dun_gemm_precision(-1) == 0
+    assert lib.dun_gemm_precision(-1) == prev
