@@ -1198,15 +1198,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(const GemmP p)
     f32x16 acc[2][4];
     seed_acc<true, 2, 4>(p, acc, m0, n0, wr, wc, li, h);
 
-    const int nh = p.K / HK;  // >= 4 (host)
+    // (split-K here, unlike the exact wide kernel: dW = dU^T H is 128 such tiles, four K ranges fill the chip)
+    const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * (p.K / p.ksplit) : 0;
+    const int nh = (p.ksplit > 1 ? p.K / p.ksplit : p.K) / HK;  // >= 4 (host)
     DmaOpW<A_KC, BM> dA;
     DmaOpW<B_KC, WBN> dB;
     dA.setup(p.A, p.lda, m0, p.M, p.K, wave, lane);
     dB.setup(p.B, p.ldb, n0, p.N, p.K, wave, lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        dA.issue(j * HK, smem + j * WSTAGE, wave);
-        dB.issue(j * HK, smem + j * WSTAGE + WA_HALF, wave);
+        dA.issue(kbeg + j * HK, smem + j * WSTAGE, wave);
+        dB.issue(kbeg + j * HK, smem + j * WSTAGE + WA_HALF, wave);
     }
     DUN_WAIT_VMCNT(12);  // half 0 landed (6 loads per half and wave)
     __builtin_amdgcn_s_barrier();
@@ -1270,8 +1272,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(const GemmP p)
             if (INFLIGHT) DUN_WAIT_VMCNT(6); else DUN_WAIT_VMCNT(0); /* half J+1 landed, J+2 may stay in flight */     \
             __builtin_amdgcn_s_barrier();                            /* everyone has read half J: its stage is free */ \
             if (ISSUE) {                                                                                               \
-                dA.issue(((J) + 3) * HK, smem + cur, wave);                                                            \
-                dB.issue(((J) + 3) * HK, smem + cur + WA_HALF, wave);                                                  \
+                dA.issue(kbeg + ((J) + 3) * HK, smem + cur, wave);                                                     \
+                dB.issue(kbeg + ((J) + 3) * HK, smem + cur + WA_HALF, wave);                                           \
             }                                                                                                          \
             DUN_X3W_READ(nxt);                                                                                         \
         }                                                                                                              \
@@ -1304,10 +1306,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_wide_kernel(const GemmP p)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[mi], vb[ni], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();
-    if (p.ev_scale != nullptr)
+    if (p.ksplit > 1) {
+        GemmP q = p;  // raw partial sum of this K range; splitk_sum_kernel adds the ranges in order
+        q.C = p.part + (size_t)blockIdx.y * p.M * p.N;
+        q.ldc = p.N;
+        q.bias = nullptr; q.relu = 0; q.R = nullptr; q.U = nullptr; q.colstats = nullptr; q.bnz = nullptr;
+        gemm_epilogue<true, 2, 4, true>(q, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    } else if (p.ev_scale != nullptr) {
         gemm_epilogue_eval<2, 4>(p, acc, smem, m0, n0, bn, tid, wr, wc, li, h);
-    else
+    } else {
         gemm_epilogue<true, 2, 4, true>(p, acc, smem, m0, n0, bm, tid, wave, wr, wc, li, h);
+    }
 }
 
 template __global__ void gemm_bf16x3_wide_kernel<true, true>(const GemmP);
@@ -1342,7 +1351,13 @@ template <bool A_KC, bool B_KC>
 static int launch_gemm(const GemmP& p, bool vec, bool dma, bool small, hipStream_t s) {
     const int grid = p.gridM * p.gridN;
     if (dma && p.x3 && p.wide) {
-        hipLaunchKernelGGL((gemm_bf16x3_wide_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16x3_wide_kernel<A_KC, B_KC>), dim3(grid, p.ksplit), dim3(256), 0, s, p);
+        if (p.ksplit > 1) {
+            const size_t n4 = (size_t)p.M * p.N / 4;
+            size_t blocks = (n4 + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.part, p.ksplit, p.M, p.N, p.C, p.ldc);
+        }
         DUN_LAUNCH_CHECK();
         return DUN_OK;
     }
@@ -1516,6 +1531,18 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     // prologue / store bubble is paid once per twice the work.  (A residual must seed the accumulators there, or be added
     // by the inference epilogue, which gathers it chunk by chunk.)
     p.x3 = (dma && gemm_precision() == 1) ? 1 : 0;
+    if (p.x3 && p.ksplit > 1 && d->N % WBN == 0 && (d->a_kcontig || !d->b_kcontig)) {
+        // exploratory kernel: K ranges on 128 x 256 tiles, as many as fill 512 workgroups and fit the workspace
+        const long long wtiles = (long long)p.gridM * (d->N / WBN);
+        int ks = (int)(512 / wtiles);
+        if (ks > 8) ks = 8;
+        while (ks > 1 && (d->K % (ks * 64) != 0 || d->splitk_ws_floats < (size_t)ks * d->M * d->N)) --ks;
+        if (ks >= 2 && d->K / ks >= 64) {
+            p.ksplit = ks;
+            p.wide = 1;
+            p.gridN = d->N / WBN;
+        }
+    }
     if (dma && p.ksplit == 1 && d->N % WBN == 0 &&
         (long long)p.gridM * (d->N / WBN) >= 512 && d->K >= 64 && (!d->R || p.rinit || d->ev_scale) &&
         (!d->U || (d->O == 1 && !d->bias && !d->relu)) &&
