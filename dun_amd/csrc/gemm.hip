@@ -702,6 +702,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     // One half tile.  NEXT: half j+1 exists; INFLIGHT: half j+2 was issued (so it may stay in flight); ISSUE: half j+3
     // exists.  Compile-time flags: a run-time branch around the fragment prefetch would make the compiler wait for
     // ALL outstanding LDS reads at the join, i.e. for the prefetch itself.
+    // (fragment reads and DMA issues spread over the gaps between the MFMAs: see DUN_WIDE_SPREAD; a group is 16 MFMAs here.
+    //  K-contiguous images are read with one ds_read_b128 per fragment, M/N-contiguous ones with two ds_read2_b32)
+    constexpr int DUN_HALF_NREAD = (A_KC ? 2 : 4) + (B_KC ? 2 : 4);
+#ifndef DUN_NO_INTERLEAVE
+#define DUN_HALF_SPREAD(NMEM, PER)                                                                                     \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int g_ = 0; g_ < (NMEM); ++g_) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);                                                         \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 - (NMEM) * (PER), 0);                                           \
+    } while (0)
+#define DUN_HALF_SEP() do { } while (0)
+#else
+#define DUN_HALF_SPREAD(NMEM, PER) do { } while (0)
+#define DUN_HALF_SEP() __builtin_amdgcn_sched_barrier(0)
+#endif
 #define DUN_HALF_STEP(J, NEXT, INFLIGHT, ISSUE)                                                                        \
     do {                                                                                                               \
         const float* a_s = smem + ((J) & 3) * STAGE;                                                                   \
@@ -710,11 +727,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
             read_frag_half<A_KC>(a_s, wr * 64 + mi * 32 + li, 1, h, fa[1][mi]);                                        \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                               \
             read_frag_half<B_KC>(b_s, wc * 64 + ni * 32 + li, 1, h, fb[1][ni]);                                        \
-        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch IN FRONT of the MFMAs it hides under */                \
+        DUN_HALF_SEP(); /* (burst form: keep the prefetch IN FRONT of the MFMAs it hides under) */                     \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
             _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
                 _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][mi][e], fb[0][ni][e], acc[mi][ni], 0, 0, 0); \
+        DUN_HALF_SPREAD(DUN_HALF_NREAD, 16 / DUN_HALF_NREAD > 3 ? 3 : 16 / DUN_HALF_NREAD);                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         DUN_WAIT_LGKMCNT0();                                                                                           \
         if (NEXT) {                                                                                                    \
@@ -732,11 +750,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                           \
                 read_frag_half<B_KC>(b_n, wc * 64 + ni * 32 + li, 0, h, fb[0][ni]);                                    \
         }                                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_HALF_SEP();                                                                                                \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
             _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
                 _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][mi][e], fb[1][ni][e], acc[mi][ni], 0, 0, 0); \
+        if (NEXT) DUN_HALF_SPREAD((ISSUE ? 4 : 0) + DUN_HALF_NREAD, 1);                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         DUN_WAIT_LGKMCNT0();                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -748,6 +767,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma4_kernel(const GemmP p) {
     if (j + 1 < nh) { DUN_HALF_STEP(j, true, false, false); ++j; } // half nh-2: the last DMA must land
     DUN_HALF_STEP(j, false, false, false);                         // half nh-1
 #undef DUN_HALF_STEP
+#undef DUN_HALF_SPREAD
+#undef DUN_HALF_SEP
     DUN_TSTAMP(2);
     __syncthreads();  // the epilogue reuses the LDS for the column statistics
     if (p.ksplit > 1) {
@@ -1080,6 +1101,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
     DUN_WAIT_LGKMCNT0();
 
     int cur = 0, nxt = WSTAGE, iss = 2 * WSTAGE;  // float offsets of the stages of half j, j+1, j+2 (a ring of three)
+    // LDS read instructions per fragment group: one ds_read_b128 per K-contiguous fragment, two ds_read2_b32 otherwise
+    constexpr int NREADW = (A_KC ? 2 : 4) + (B_KC ? 4 : 8);
 // timing experiments only (results are wrong): what the mid-step barrier / the operand DMA / the fragment reads cost
 #ifdef DUN_EXP_NODMA
 #define DUN_EXP_DMA false
@@ -1096,6 +1119,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
 #else
 #define DUN_WIDE_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
+#ifndef DUN_NO_INTERLEAVE  // (A/B build: -DDUN_NO_INTERLEAVE restores the burst in front of the group)
+// Fragment reads (and, behind the barrier, the DMA issues) are SPREAD over the gaps between the group's MFMAs -- one LDS read
+// or DMA issue per PER MFMAs -- instead of going out as one burst in front of them: the two waves of a SIMD share its issue
+// port, and a burst of 12 reads + 6 DMA issues holds it while the partner wave's MFMAs wait for their slot.  Forward 3.795 ->
+// 3.693 ms, dX 3.845 -> 3.724 ms on one box (0.946 / 0.938 of peak with their epilogues).
+#define DUN_WIDE_SPREAD(NMEM, PER)                                                                                     \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int g_ = 0; g_ < (NMEM); ++g_) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);                                                         \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 32 - (NMEM) * (PER), 0);                                           \
+    } while (0)
+#define DUN_WIDE_SEP() do { } while (0)
+#else
+#define DUN_WIDE_SPREAD(NMEM, PER) do { } while (0)
+#define DUN_WIDE_SEP() __builtin_amdgcn_sched_barrier(0)
+#endif
 #define DUN_WIDE_STEP(J, NEXT, INFLIGHT, ISSUE)                                                                                 \
     do {                                                                                                               \
         const float* a_s = smem + cur;                                                                                 \
@@ -1106,11 +1147,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                               \
             read_frag_w<B_KC, WBN>(b_s, wc * 128 + ni * 32 + li, 1, h, fb[1][ni]);                                     \
         }                                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_WIDE_SEP();                                                                                                \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
             _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
                 _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                       \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][mi][e], fb[0][ni][e], acc[mi][ni], 0, 0, 0); \
+        DUN_WIDE_SPREAD(NREADW, 32 / NREADW > 4 ? 4 : 32 / NREADW);                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         DUN_WAIT_LGKMCNT0();                                                                                           \
         if (NEXT) {                                                                                                    \
@@ -1129,11 +1171,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_wide_kernel(const GemmP p) {
                 read_frag_w<B_KC, WBN>(b_n, wc * 128 + ni * 32 + li, 0, h, fb[0][ni]);                                 \
             }                                                                                                          \
         }                                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        DUN_WIDE_SEP();                                                                                                \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                  \
             _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                           \
                 _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                       \
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][mi][e], fb[1][ni][e], acc[mi][ni], 0, 0, 0); \
+        if (NEXT) DUN_WIDE_SPREAD((ISSUE ? 6 : 0) + NREADW, 32 / (6 + NREADW));                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         DUN_WAIT_LGKMCNT0();                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
