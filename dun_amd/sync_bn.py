@@ -66,6 +66,13 @@ class SyncBatchNorm2d(nn.BatchNorm2d):
 
     _dun_dist = None
 
+    def __getstate__(self):
+        # a pickled model (BaseNet.save) does not carry its communicator: loaded again it is a plain BatchNorm2d until
+        # shard() binds it to the process group of the job that loaded it
+        st = self.__dict__.copy()
+        st["_dun_dist"] = None
+        return st
+
     def forward(self, x):
         spec = self._dun_dist
         if not self.training or spec is None or (spec.world == 1 and not spec.force_collectives) or not spec.sync_bn:

@@ -418,6 +418,10 @@ def test_sync_batchnorm2d_gradients_match_full_batch_autograd():
                          (ref.running_mean, mine[0].running_mean), (ref.running_var, mine[0].running_var)):
                 assert float((a - b).detach().abs().max()) <= tol * max(1.0, float(a.detach().abs().max()))
             assert int(mine[0].num_batches_tracked) == 1
+            import pickle
+            again = pickle.loads(pickle.dumps(mine))      # (written by this test) the communicator does not travel
+            assert again[0]._dun_dist is None and mine[0]._dun_dist is spec
+            assert torch.equal(again[0].running_var, mine[0].running_var)
             mine[0].load_state_dict(ref.state_dict())
             mine.eval(); ref.eval()
             assert torch.equal(mine(x), ref(x))          # eval mode is nn.BatchNorm2d's own path
