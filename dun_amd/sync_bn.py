@@ -17,7 +17,6 @@ Running statistics are updated from the global batch (unbiased variance), as a s
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 class _SyncBN2dFn(torch.autograd.Function):
