@@ -180,6 +180,8 @@ def gemm_kernel_name(M, N, K, a_kc, b_kc, plain_few_tiles=False):
         wide = N % 256 == 0 and (M // 128) * (N // 256) >= 512 and not plain_few_tiles and (a_kc or not b_kc)
         if wide:
             return "gemm_f32_wide_kernel<A_KC=%d,B_KC=%d> (128x256 tiles)" % (a_kc, b_kc)
+        if plain_few_tiles and N % 256 == 0 and (a_kc or not b_kc) and (M // 128) * (N // 256) <= 256:
+            return "gemm_f32_wide_kernel<A_KC=%d,B_KC=%d> (128x256 tiles, K ranges filling 512 workgroups)" % (a_kc, b_kc)
         return "gemm_f32_dma4_kernel<A_KC=%d,B_KC=%d>" % (a_kc, b_kc)
     mi = 1 if small else 2
     return "gemm_f32_kernel<A_KC=%d,B_KC=%d,MI=%d> (%dx%d tiles)" % (a_kc, b_kc, mi, 64 * mi, 64 * mi)
