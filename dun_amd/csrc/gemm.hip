@@ -1599,7 +1599,12 @@ int gemm_f32(const dun_gemm_desc* d, hipStream_t s) {
     // prologue / store bubble is paid once per twice the work.  (A residual must seed the accumulators there, or be added
     // by the inference epilogue, which gathers it chunk by chunk.)
     p.x3 = (dma && gemm_precision() == 1) ? 1 : 0;
-    if (p.ksplit > 1 && d->N % WBN == 0 && (d->a_kcontig || !d->b_kcontig)) {
+#ifdef DUN_NO_WIDE_SPLITK  // A/B build
+    const bool wide_splitk = p.x3 != 0;
+#else
+    const bool wide_splitk = true;
+#endif
+    if (wide_splitk && p.ksplit > 1 && d->N % WBN == 0 && (d->a_kcontig || !d->b_kcontig)) {
         // K ranges on 128 x 256 tiles, as many as fill 512 workgroups and fit the workspace (dW = dU^T H: 128 tiles x 4
         // ranges; 3.79 -> 3.73 ms against two ranges on 128 x 128 tiles: fewer fragment reads and DMA issues per MFMA)
         const long long wtiles = (long long)p.gridM * (d->N / WBN);
