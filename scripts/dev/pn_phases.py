@@ -13,7 +13,7 @@ buf = net.model._get_buffers(512, 10, True)
 P = 32
 if len(sys.argv) > 1 and sys.argv[1] == "bwd":
     # the last launch that stamped was the backward: same stamp area
-    raw = buf.sync.view(torch.int32)[64:].view(2, P, 128, 4)[:, :, 104:, :].contiguous().view(torch.int64).view(2, P, 48)
+    raw = buf.sync.view(torch.int32)[64:64 + 2 * P * 128 * 4].view(2, P, 128, 4)[:, :, 104:, :].contiguous().view(torch.int64).view(2, P, 48)
     st = torch.cat([raw[0], raw[1]], dim=1).cpu().double()
     for pid in (0, 15, 31):
         s = st[pid]
@@ -29,7 +29,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "bwd":
 from dun_amd import kernels
 kernels.backend().fc_forward(buf)  # (the backward stamps the same area: run the forward once more, same launch as in fit)
 torch.cuda.synchronize()
-raw = buf.sync.view(torch.int32)[64:].view(2, P, 128, 4)[:, :, 104:, :].contiguous().view(torch.int64).view(2, P, 48)
+raw = buf.sync.view(torch.int32)[64:64 + 2 * P * 128 * 4].view(2, P, 128, 4)[:, :, 104:, :].contiguous().view(torch.int64).view(2, P, 48)
 st = torch.cat([raw[0], raw[1]], dim=1).cpu().double()  # [P, 96]
 for pid in (0, 15, 31):
     s = st[pid]
