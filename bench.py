@@ -445,7 +445,7 @@ def parse_args(argv=None):
                          "reference's wrapper sets it) instead of immediate mode; minutes of extra warm-up on a cold box")
     ap.add_argument("--channels-last", action="store_true",
                     help="image workloads: NHWC conv trunk; the head/ELBO path is unaffected (measured SLOWER with MIOpen's "
-                         "immediate mode on fp32: 13.0 s vs 2.85 s per c5_cifar step -- off by default)")
+                         "immediate mode on fp32: 13.0 s vs 1.58 s per c5_cifar step -- off by default)")
     return ap.parse_args(argv)
 
 
