@@ -441,3 +441,21 @@ def test_file_based_toy_loaders(tmp_path):
         assert t.shape == (250, 1) and t.dtype == np.float32 and np.array_equal(t[:, 0], my[:, i].astype(np.float32))
     with pytest.raises(FileNotFoundError):
         load_agw_1d(os.path.join(base, "nowhere"))
+
+
+def test_image_module_takes_winograd_out_of_miopens_selection_unless_the_user_chose():
+    """dun_amd.stochastic_img_resnets sets MIOPEN_DEBUG_CONV_WINOGRAD=0 at import (the fp32 Winograd
+    solver MIOpen picks for the 3x3 convolutions on gfx950 takes half of a c5_cifar step); a value already in the
+    environment stays."""
+    import subprocess
+    import sys
+    code = "import os, dun_amd.stochastic_img_resnets; print(os.environ.get('MIOPEN_DEBUG_CONV_WINOGRAD'))"
+    env = {k: v for k, v in os.environ.items() if k != "MIOPEN_DEBUG_CONV_WINOGRAD"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "0"
+    env["MIOPEN_DEBUG_CONV_WINOGRAD"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "1"
