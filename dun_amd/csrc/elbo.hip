@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
                                                             double* __restrict__ partials, int nparts,
                                                             int q_is_logits, float* __restrict__ q_out,
                                                             const float* __restrict__ obj_src,
-                                                            double* __restrict__ obj_dst, double* done) {
+                                                            double* __restrict__ obj_dst, double* done,
+                                                            const float* __restrict__ noise_log_std) {
     __shared__ double red[4];
     __shared__ float s_q[256];
     const int tid = threadIdx.x;
@@ -503,7 +504,8 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
     // what depends on nothing goes out first: at the sizes of a training step's metric pass (one workgroup, a few KB) the
     // kernel is a chain of memory round trips, and every load issued late is one more of them
     float yv[4] = {0.f, 0.f, 0.f, 0.f};
-    float ls = 0.f;
+    float ls = 0.f, nls = 0.f;
+    if (noise_log_std) nls = noise_log_std[0];
     if (partials) {
         ls = log_std[0];
 #pragma unroll
@@ -576,7 +578,14 @@ __global__ __launch_bounds__(256) void predict_gauss_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) {
             if (idx + e < n) {
                 mean[idx + e] = mu[e];
-                if (std) std[idx + e] = sd[e];
+                if (std) {
+                    float so = sd[e];
+                    if (noise_log_std) {  // (model_std ** 2 + log_std.exp() ** 2).pow(0.5), training_wrappers.py:153
+                        const float sg = expf(nls);
+                        so = sqrtf(rounded(so * so) + rounded(sg * sg));
+                    }
+                    std[idx + e] = so;
+                }
             }
         }
         if (partials) {
@@ -1143,15 +1152,17 @@ static int predict_gauss_impl(const float* act, const float* q, int q_is_logits,
     // one workgroup: its [2][1] partials ARE the metric sums, no reduction launch
     double* part = metrics ? (nparts == 1 ? metrics : partials) : nullptr;
     const bool vec = (n % 4 == 0) && aligned16(act);
+    // log_std without targets: no metrics, `std` is the TOTAL predictive std (model spread + observation noise)
+    const float* noise = (y == nullptr && std != nullptr) ? log_std : nullptr;
     if (vec && stream_nt((size_t)D * n * 4))
         hipLaunchKernelGGL((predict_gauss_kernel<true, true>), dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done, noise);
     else if (vec)
         hipLaunchKernelGGL(predict_gauss_kernel<true>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done, noise);
     else
         hipLaunchKernelGGL(predict_gauss_kernel<false>, dim3(nparts), dim3(256), 0, s, act, q, D, n, mean, std, y,
-                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done);
+                           log_std, part, nparts, q_is_logits, q_out, obj_src, obj_dst, done, noise);
     DUN_LAUNCH_CHECK();
     if (metrics && nparts > 1) {
         hipLaunchKernelGGL(reduce_rows_f64_kernel, dim3(2), dim3(64), 0, s, partials, nparts, metrics);

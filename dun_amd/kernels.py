@@ -219,7 +219,9 @@ class HipBackend(object):
         return res
 
     def predict(self, act, q, regression, get_std=False, y=None, log_std=None, metrics_out=None):
-        """Depth-marginal prediction; with y also the metric sums (double [2], written into `metrics_out` if given)."""
+        """Depth-marginal prediction; with y also the metric sums (double [2], written into `metrics_out` if given).
+        Regression with ``log_std`` but without ``y``: the returned std is the total predictive one,
+        sqrt(model_std^2 + exp(log_std)^2), from the same launch."""
         lib = L.lib()
         dev = act.device
         D = act.shape[0]
@@ -245,7 +247,7 @@ class HipBackend(object):
                 partials = torch.empty(2, nparts, device=dev, dtype=torch.float64)
                 metrics = metrics_out if metrics_out is not None else torch.empty(2, device=dev, dtype=torch.float64)
             L.check(lib.dun_predict_gauss(L.f32(act), L.f32(q), D, n, L.f32(mean), None if std is None else L.f32(std),
-                                          None if y is None else L.f32(y), None if y is None else L.f32(log_std),
+                                          None if y is None else L.f32(y), None if log_std is None else L.f32(log_std),
                                           None if partials is None else L.ptr(partials),
                                           None if metrics is None else L.ptr(metrics), s), "dun_predict_gauss")
             return mean, std, metrics

@@ -299,10 +299,17 @@ class depth_categorical(nn.Module):
         return joint_loglike_per_depth + self.logprior - log_marginal_over_depth
 
     @staticmethod
-    def marginalise_d_predict(act_vec, d_posterior, depth=None, softmax=False, get_std=False):
-        """Predict while marginalising d with the given distribution (fused kernel, no autograd)."""
+    def marginalise_d_predict(act_vec, d_posterior, depth=None, softmax=False, get_std=False, noise_log_std=None):
+        """Predict while marginalising d with the given distribution (fused kernel, no autograd).
+        ``noise_log_std`` (not in the reference's signature; regression with get_std): the std handed back is the total
+        predictive one, sqrt(model_std^2 + exp(noise_log_std)^2) -- what DUN.predict adds behind this call
+        (src/DUN/training_wrappers.py:153), taken in the predictor's own launch."""
         assert not (softmax and get_std)
         act = act_vec.detach().to(torch.float32).contiguous()
+        if noise_log_std is not None and get_std and not softmax:
+            out, std, _ = kernels.backend().predict(act, d_posterior, regression=True, get_std=True,
+                                                    log_std=noise_log_std.detach().to(torch.float32).reshape(-1))
+            return out, std
         out, std, _ = kernels.backend().predict(act, d_posterior, regression=not softmax, get_std=get_std)
         if get_std:
             return out, std

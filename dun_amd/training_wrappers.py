@@ -354,13 +354,16 @@ class DUN(BaseNet):
             x, = to_variable(var=(x,), cuda=self.cuda)
             act_vec = self.model.forward(x, depth=depth).data
             if get_std:
-                pred_mu, model_std = depth_categorical.marginalise_d_predict(
+                # (model_std ** 2 + log_std.exp() ** 2).pow(0.5) of the reference (src/DUN/training_wrappers.py:153) is
+                # taken inside the predictor's launch: five element-wise launches fewer per call
+                noise = None if (return_model_std or not self.regression) else self.f_neg_loglike.log_std
+                fused = noise is not None and noise.numel() == 1
+                pred_mu, std = depth_categorical.marginalise_d_predict(
                     act_vec, self.prob_model.current_posterior, depth=depth, softmax=(not self.regression),
-                    get_std=get_std)
-                if return_model_std:
-                    return pred_mu.data, model_std.data
-                pred_std = (model_std ** 2 + self.f_neg_loglike.log_std.exp() ** 2).pow(0.5)
-                return pred_mu.data, pred_std.data
+                    get_std=get_std, noise_log_std=noise if fused else None)
+                if noise is not None and not fused:
+                    std = (std ** 2 + noise.exp() ** 2).pow(0.5)
+                return pred_mu.data, std.data
             probs = depth_categorical.marginalise_d_predict(act_vec, self.prob_model.current_posterior, depth=depth,
                                                             softmax=(not self.regression), get_std=get_std)
             return probs.data

@@ -126,7 +126,10 @@ int dun_elbo_gauss_static(const float* act, const float* y, const float* log_std
  * Gaussian: act [D,n] (n = B*O), q [D] probabilities -> mean [n], std [n] (nullable) = sqrt(sum q a^2 - mean^2)
  *   (NaN for a negative variance, as model_var.pow(0.5) in the reference).
  *   metrics (nullable, double [2]; needs y [n] and log_std [1]): sum_b NLL(mean, y, sqrt(sigma^2 + std^2)),
- *   sum_b (mean - y)^2.  Overwritten (no need to zero it); partials: double [2][dun_predict_num_partials(n, 1)]. */
+ *   sum_b (mean - y)^2.  Overwritten (no need to zero it); partials: double [2][dun_predict_num_partials(n, 1)].
+ *   log_std WITHOUT y (y = metrics = partials = NULL): `std` receives the total predictive std
+ *   sqrt(std^2 + exp(log_std)^2), i.e. DUN.predict(get_std=True) of src/DUN/training_wrappers.py:153 in the same launch
+ *   (the step entries below always write the model std: their log_std belongs to the metrics). */
 int dun_predict_gauss(const float* act, const float* q, int D, int n, float* mean, float* std, const float* y,
                       const float* log_std, double* partials, double* metrics, dun_stream_t stream);
 /* dun_predict_gauss for the end of a training step (src/DUN/training_wrappers.py:229-245): q may be given as logits

@@ -158,6 +158,8 @@ class CpuBackend(object):
                 metrics = torch.stack([nll.double().sum(), ((mu - y).double() ** 2).sum()])
                 if metrics_out is not None:
                     metrics = metrics_out.copy_(metrics)
+            if y is None and log_std is not None:  # total predictive std (dun_predict_gauss: log_std without targets)
+                std = (std ** 2 + log_std.exp() ** 2).pow(0.5)
             return mu, (std if (get_std or y is not None) else None), metrics
         probs = (qb * F.softmax(act, dim=2)).sum(0)
         metrics = None

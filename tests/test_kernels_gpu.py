@@ -367,6 +367,25 @@ def test_predict_gauss(be, tag):
         assert abs(m[0].item() - nll) < 1e-4 * abs(nll) + 1e-6 and abs(m[1].item() - se) < 1e-5 * se + 1e-9
 
 
+@pytest.mark.parametrize("n", [1, 7, 512, 4099, 65536])
+def test_predict_gauss_total_std(be, n):
+    """log_std without targets: std is DUN.predict's (model_std ** 2 + log_std.exp() ** 2).pow(0.5)
+    (src/DUN/training_wrappers.py:153), mean and model std as without it; every kernel variant (scalar / vector /
+    streaming loads, one and several workgroups)."""
+    g = torch.Generator().manual_seed(n)
+    D = 11
+    act = torch.randn(D, n, 1, generator=g)
+    q = torch.softmax(torch.randn(D, generator=g), 0)
+    for lsv in (-2.5, 0.3):
+        ls = torch.tensor([lsv])
+        mean0, std0, _ = be.predict(dev(act), dev(q), True, get_std=True)
+        mean1, std1, m = be.predict(dev(act), dev(q), True, get_std=True, log_std=dev(ls))
+        assert m is None and torch.equal(mean0, mean1)
+        want = (std0.cpu() ** 2 + ls.exp() ** 2).pow(0.5)
+        assert rel_err(std1.cpu(), want) < 1e-6
+        assert float((std1.cpu() - want).abs().max()) <= 2.4e-7 * float(want.abs().max())  # 2 ulp
+
+
 # ------------------------------------------------------------------------------------------------------
 # shared head
 # ------------------------------------------------------------------------------------------------------
