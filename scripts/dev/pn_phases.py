@@ -26,6 +26,26 @@ if len(sys.argv) > 1 and sys.argv[1] == "bwd":
                      (s[b + 4] - s[b + 3]) / 100, (nxt - s[b + 4]) / 100, (s[b] - s[90]) / 100))
         print("  total %.2f us" % ((s[94] - s[90]) / 100))
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "eval":
+    # eval-mode forward (no exchange): block start -> normalised -> barrier
+    net.model.eval()
+    with torch.no_grad():
+        for _ in range(5):
+            net.model.forward(x)
+    torch.cuda.synchronize()
+    ebuf = net.model._get_buffers(512, 10, False)
+    raw = ebuf.sync.view(torch.int32)[64:64 + 2 * P * 128 * 4].view(2, P, 128, 4)[:, :, 104:, :].contiguous().view(torch.int64).view(2, P, 48)
+    st = torch.cat([raw[0], raw[1]], dim=1).cpu().double()
+    for pid in (0, 15, 31):
+        s = st[pid]
+        print("wg %d: entry->coef %.2f  input layer %.2f  head0+barrier %.2f" % (pid, (s[91] - s[90]) / 100, (s[0] - s[91]) / 100, (s[1] - s[0]) / 100))
+        for i in range(10):
+            b = 2 + 6 * i
+            print("  block %d: mm+head+norm+store %.2f  barrier %.2f  (to next block start %.2f) | t=%.2f"
+                  % (i, (s[b + 4] - s[b]) / 100, (s[b + 5] - s[b + 4]) / 100,
+                     ((s[b + 6] if i < 9 else s[92]) - s[b + 5]) / 100, (s[b] - s[90]) / 100))
+        print("  tail %.2f  total %.2f us" % ((s[94] - s[92]) / 100, (s[94] - s[90]) / 100))
+    sys.exit(0)
 from dun_amd import kernels
 kernels.backend().fc_forward(buf)  # (the backward stamps the same area: run the forward once more, same launch as in fit)
 torch.cuda.synchronize()
