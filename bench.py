@@ -420,8 +420,9 @@ def _claim_stdout():
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 5; 500 for the small-net workload c2_uci, whose step is ~0.13 ms)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 2; 30 for c2_uci)")
     ap.add_argument("--workload", default="c3_wide", choices=sorted(WORKLOADS) + sorted(IMAGE_WORKLOADS))
     ap.add_argument("--no-sync-bn", action="store_true", help="per-replica BatchNorm statistics (not matched numerics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -446,7 +447,13 @@ def parse_args(argv=None):
     ap.add_argument("--channels-last", action="store_true",
                     help="image workloads: NHWC conv trunk; the head/ELBO path is unaffected (measured SLOWER with MIOpen's "
                          "immediate mode on fp32: 13.0 s vs 1.58 s per c5_cifar step -- off by default)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    small = args.workload == "c2_uci" and not args.predict
+    if args.steps is None:
+        args.steps = 500 if small else 5
+    if args.warmup is None:
+        args.warmup = 30 if small else 2
+    return args
 
 
 def _free_port():
