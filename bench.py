@@ -443,7 +443,9 @@ def parse_args(argv=None):
                          "of fit; prints the same JSON line with metric 'DUN predict samples/sec'")
     ap.add_argument("--miopen-benchmark", action="store_true",
                     help="image workloads: let MIOpen search per conv shape (torch.backends.cudnn.benchmark, as the "
-                         "reference's wrapper sets it) instead of immediate mode; minutes of extra warm-up on a cold box")
+                         "reference's wrapper sets it) instead of immediate mode; on a cold box the search of the 12-exit "
+                         "ResNet-50 at batch 4096 had not finished its first step after 18 minutes (round 3) -- a line a "
+                         "minute on stderr says the run is alive")
     ap.add_argument("--channels-last", action="store_true",
                     help="image workloads: NHWC conv trunk; the head/ELBO path is unaffected (measured SLOWER with MIOpen's "
                          "immediate mode on fp32: 13.0 s vs 1.58 s per c5_cifar step -- off by default)")
@@ -588,6 +590,17 @@ def run_rank(args):
             torch.cuda.synchronize()
 
     if image:
+        if args.miopen_benchmark and rank == 0:
+            # MIOpen's per-shape search runs inside the first step and says nothing for minutes: a line a minute on
+            # stderr tells whoever watches the run (and gpurun's silence limit) that it is alive
+            import threading
+
+            def heartbeat():
+                t_start = time.perf_counter()
+                while True:
+                    time.sleep(60.0)
+                    print("[bench] alive, %.0f s" % (time.perf_counter() - t_start), file=sys.stderr, flush=True)
+            threading.Thread(target=heartbeat, daemon=True).start()
         net = build_image_net(channels, N_train)
         torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
         g = torch.Generator().manual_seed(rank)
