@@ -26,6 +26,10 @@ from . import kernels
 # (profiles/r03_bench_c5_*).  Exact fp32 products instead of Winograd's transformed ones -- no looser than before.  MIOpen
 # reads the variable at its first convolution; a value the user has set stays.
 os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+# The 1x1 convolutions at small batches (c4_mnist: batch 256): MIOpen's choice is its rocBLAS GEMM solver (Cijk_* kernels,
+# a fifth of the step); without it they go to the same implicit-GEMM kernels: 113.1 -> 102.6 ms per c4_mnist step, c5_cifar
+# unchanged (1568 ms either way).  Same rule: the user's value stays.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_GEMM", "0")
 
 __all__ = ['ResNet', 'ArchUncertResNet', 'resnet18', 'resnet34', 'resnet50', 'resnet101']
 

@@ -449,8 +449,9 @@ def test_image_module_takes_winograd_out_of_miopens_selection_unless_the_user_ch
     environment stays."""
     import subprocess
     import sys
-    code = "import os, dun_amd.stochastic_img_resnets; print(os.environ.get('MIOPEN_DEBUG_CONV_WINOGRAD'))"
-    env = {k: v for k, v in os.environ.items() if k != "MIOPEN_DEBUG_CONV_WINOGRAD"}
+    code = ("import os, dun_amd.stochastic_img_resnets; assert os.environ.get('MIOPEN_DEBUG_CONV_GEMM') == '0'; "
+            "print(os.environ.get('MIOPEN_DEBUG_CONV_WINOGRAD'))")
+    env = {k: v for k, v in os.environ.items() if k not in ("MIOPEN_DEBUG_CONV_WINOGRAD", "MIOPEN_DEBUG_CONV_GEMM")}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
