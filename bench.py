@@ -20,9 +20,18 @@ import os
 import sys
 import time
 
-# image workloads: MIOpen's default exhaustive find takes minutes per ResNet-50 DUN on a cold box; the fast find
-# mode picks from its heuristics instead (set before MIOpen loads; an explicit setting wins)
+# image workloads: MIOpen's default (hybrid) find measures the applicable solvers once per convolution shape -- about
+# four minutes of warm-up for the 12-exit ResNet-50 at batch 4096 on a cold box -- so the benchmark asks for the FAST mode,
+# which picks from heuristics without measuring (set before MIOpen loads; an explicit setting wins).  Those heuristics
+# pick badly on gfx950 for fp32: the Winograd assembly solver (vector ALUs, 11.9 ms per call, half of the step) for the
+# 3x3 convolutions at batch 4096, and the rocBLAS-GEMM solver for the 1x1 ones at batch 256, where the measured find
+# lands on the implicit-GEMM MFMA kernels; with both solver families out of the selection FAST picks what the find
+# picks: c5_cifar 2845 -> 1578 ms per step (hybrid find: 1580), c4_mnist 113.1 -> 102.4 (hybrid find, which keeps
+# Winograd and GEMM where they measure faster: 97.4).  `MIOPEN_FIND_MODE=DYNAMIC_HYBRID python bench.py ...` gives those.
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+if os.environ["MIOPEN_FIND_MODE"] == "FAST":
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_GEMM", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -590,9 +599,10 @@ def run_rank(args):
             torch.cuda.synchronize()
 
     if image:
-        if args.miopen_benchmark and rank == 0:
-            # MIOpen's per-shape search runs inside the first step and says nothing for minutes: a line a minute on
-            # stderr tells whoever watches the run (and gpurun's silence limit) that it is alive
+        if rank == 0:
+            # MIOpen's per-shape search (--miopen-benchmark, or a find mode other than FAST in the environment) runs inside
+            # the first step and says nothing for minutes: a line a minute on stderr tells whoever watches the run (and
+            # gpurun's silence limit) that it is alive
             import threading
 
             def heartbeat():

@@ -10,8 +10,6 @@ the resulting ``act_vec`` is the fused kernel of dun_amd/probability.py.
 Module names and registration order follow the reference so that ``state_dict()`` keys are interchangeable and
 the same torch seed yields the same initial weights.
 """
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -19,17 +17,6 @@ from torch.nn.modules.dropout import _DropoutNd
 
 from . import kernels
 
-# The trunk's 3x3 convolutions: left to itself MIOpen (ROCm 7.2, fp32, NCHW) answers them on gfx950 with its fp32
-# Winograd assembly solver (miopenSp3AsmConv_v30_3_1_gfx9_fp32_f2x3: vector ALUs, 11.9 ms per call at the C5 shapes,
-# half of the step) where its gfx950 implicit-GEMM MFMA kernels (igemm_*_gtcx35_nhwc_fp32) take 2.3-2.5 ms for the same
-# call; with the Winograd solvers taken out of the selection a c5_cifar step goes from 2845 to 1572 ms
-# (profiles/r03_bench_c5_*).  Exact fp32 products instead of Winograd's transformed ones -- no looser than before.  MIOpen
-# reads the variable at its first convolution; a value the user has set stays.
-os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
-# The 1x1 convolutions at small batches (c4_mnist: batch 256): MIOpen's choice is its rocBLAS GEMM solver (Cijk_* kernels,
-# a fifth of the step); without it they go to the same implicit-GEMM kernels: 113.1 -> 102.6 ms per c4_mnist step, c5_cifar
-# unchanged (1568 ms either way).  Same rule: the user's value stays.
-os.environ.setdefault("MIOPEN_DEBUG_CONV_GEMM", "0")
 
 __all__ = ['ResNet', 'ArchUncertResNet', 'resnet18', 'resnet34', 'resnet50', 'resnet101']
 

@@ -52,7 +52,12 @@ class DUN(BaseNet):
         if self.cuda:
             self.model.cuda()
             self.f_neg_loglike.cuda()
-            torch.backends.cudnn.benchmark = True  # MIOpen find mode for the conv trunks of image DUNs
+            # The reference sets cudnn.benchmark = True here (src/DUN/training_wrappers.py:45): on cuDNN a cheap per-shape
+            # algorithm pick.  On MIOpen the same flag asks for the EXHAUSTIVE search -- the first step of the 12-exit
+            # ResNet-50 at batch 4096 had not finished after 18 minutes on a cold box -- while with the flag off torch's
+            # MIOpen path still runs MIOpen's find in its default (hybrid) mode, which measures the applicable solvers once
+            # per shape (about four minutes for that net on a cold box, seconds for the MNIST one, cached per user
+            # afterwards) and lands on the same kernels.  So the flag is left as the caller has it.
         print('    Total params: %.2fM' % (self.get_nb_parameters() / 1000000.0))
 
     def create_opt(self):
