@@ -42,7 +42,7 @@ def build(c, cuda):
     net = quiet(DUN_VI, model, pm, meta["N"], lr=meta["lr"], momentum=meta["momentum"], weight_decay=meta["wd"],
                 cuda=cuda, regression=False)
     pm.q_logits.data.copy_(c.t("q_logits0"))
-    torch.backends.cudnn.benchmark = False  # (the wrapper turns MIOpen's benchmark search on, as the reference does)
+    torch.backends.cudnn.benchmark = False  # (never MIOpen's exhaustive search in a test, whatever the process had)
     return net, meta
 
 
