@@ -115,9 +115,9 @@ def build_image_net(channels, N_train):
     D = model.n_layers
     pm = quiet(depth_categorical_VI, [1.0 / D] * D, cuda=True)
     net = quiet(DUN_VI, model, pm, N_train, lr=0.1, momentum=0.9, weight_decay=1e-4, cuda=True, regression=False)
-    # the wrapper enables MIOpen's per-shape benchmark search like the reference; on a cold box that search (and the
-    # kernel compiles behind it) takes many minutes for the ~100 conv shapes of a 12-exit ResNet-50: use MIOpen's
-    # immediate mode for the benchmark so the default run finishes within minutes.  The conv trunk is not ours.
+    # never MIOpen's exhaustive per-shape search unless --miopen-benchmark asks for it (more than 18 minutes for the first
+    # step of this net at batch 4096 on a cold box); the find mode is the environment's (FAST by default here, see the top
+    # of this file).  The conv trunk is not ours.
     torch.backends.cudnn.benchmark = False
     return net
 
