@@ -457,7 +457,8 @@ def parse_args(argv=None):
                          "minute on stderr says the run is alive")
     ap.add_argument("--channels-last", action="store_true",
                     help="image workloads: NHWC conv trunk; the head/ELBO path is unaffected (measured SLOWER with MIOpen's "
-                         "immediate mode on fp32: 13.0 s vs 1.58 s per c5_cifar step -- off by default)")
+                         "FAST find mode on fp32: 13.0 s vs 1.58 s per c5_cifar step; with MIOPEN_FIND_MODE=DYNAMIC_HYBRID "
+                         "1.80 s vs 1.58 s, MIOpen's NHWC BatchNorm costing more than the transposes saved -- off by default)")
     args = ap.parse_args(argv)
     small = args.workload == "c2_uci" and not args.predict
     if args.steps is None:
